@@ -1,0 +1,170 @@
+/* rt_amd.h - C ABI of the MI355X (gfx950) render path.
+ *
+ * One shared library, librt_amd.so, exports exactly the symbols declared here.  The reference
+ * renderer (zkkv/raytracer) has no FFI layer: its seam is the C++ interface BVHInterface /
+ * renderImage / Screen.  Each entry point below names the reference interface it stands in for
+ * (file:line relative to the reference tree); a binding on the reference side hands over the
+ * spans and PODs those interfaces already hold.
+ *
+ * Conventions: every function returns an rt_status (0 = ok) unless stated; rt_last_error() gives
+ * the message of the calling thread's last failure; nothing throws across this boundary; all
+ * pointers are plain host pointers unless a parameter is documented as a device pointer.  Calls
+ * on one rt_scene must be serialised by the caller; different scenes / devices are independent.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,     /* bad argument (null pointer, size mismatch, index out of range) */
+    RT_ERR_HIP = 2,         /* a HIP runtime call failed; message holds hipGetErrorString */
+    RT_ERR_UNSUPPORTED = 3, /* a feature flag this build does not implement on the GPU */
+    RT_ERR_NOMEM = 4,
+    RT_ERR_LIMIT = 5        /* a size beyond a documented limit (tree depth, leaf size, filter size) */
+} rt_status;
+
+/* POD mirror of Features + ExtraFeatures (src/common.h:62-115).  int32 for every bool. */
+typedef struct rt_features {
+    int32_t enableShading, enableReflections, enableShadows, enableNormalInterp, enableTextureMapping;
+    int32_t enableAccelStructure, enableBilinearTextureFiltering, enableTransparency, enableJitteredSampling;
+    int32_t shadingModel;      /* ShadingModel: 0 Lambertian, 1 Phong, 2 BlinnPhong, 3 LinearGradient */
+    uint32_t numPixelSamples;  /* 1 */
+    uint32_t numShadowSamples; /* 4 */
+    int32_t enableBloomEffect, enableGlossyReflection;
+    uint32_t bloomFilterSize;  /* 15, at most 30 (src/extra.cpp:358) */
+    float bloomFilterThreshold, bloomFilterIntensity; /* 0.5, 0.8 */
+    uint32_t numGlossySamples; /* 1 */
+    int32_t reserved[2];
+} rt_features;
+
+/* Camera state the reference recomputes per ray inside Trackball::generateRay
+ * (framework/src/trackball.cpp:71-74, 101-110): position() and quat(eulerAngles), plus the
+ * half extents of the image plane (trackball.cpp:26-27). */
+typedef struct rt_camera {
+    float position[3];
+    float quat[4]; /* w, x, y, z */
+    float halfWidth, halfHeight;
+} rt_camera;
+
+/* Which rows of the frame this call renders: rows are cut into stripes of `stripeRows` rows and
+ * stripe s belongs to rank (s % world).  {0,0,1} or a null pointer = the whole frame. */
+typedef struct rt_region {
+    int32_t stripeRows;
+    int32_t rank;
+    int32_t world;
+} rt_region;
+
+/* Ray counters of the last render on a scene: one ray = one closest-hit query that contributes to
+ * the image (the reference's unused glossy debug query, src/extra.cpp:510-511, is not traced). */
+typedef struct rt_stats {
+    uint64_t primaryRays, shadowRays, secondaryRays;
+    uint64_t nodePairSteps, triangleTests; /* filled only by rt_render with RT_RENDER_COUNT_WORK */
+    uint64_t pixels;
+    uint64_t stackOverflows; /* must be 0 */
+    uint64_t reserved;
+} rt_stats;
+
+enum {
+    RT_MAX_RAY_DEPTH = 6,      /* recursion continues while rayDepth < 6 (src/recursive.cpp:62) */
+    RT_RENDER_COUNT_WORK = 1,  /* flag: also count node-pair steps and triangle tests (slower) */
+    RT_RENDER_NO_CULL = 2      /* flag: visit every box the ray enters, as the reference does
+                                  (src/bvh.cpp:289-297), instead of skipping boxes beyond the closest hit */
+};
+
+typedef struct rt_bvh rt_bvh;     /* host-side BVH in the reference's node / primitive layout */
+typedef struct rt_scene rt_scene; /* device-resident flattened scene */
+
+const char* rt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host side (no GPU needed)
+ * ------------------------------------------------------------------------------------------- */
+
+/* BVH::BVH(scene, features) with median split (src/bvh.cpp:48-95, 429-512).  prims = the scene's
+ * triangles as BVHInterface::Primitive records (100 bytes: meshID, 3 x {position, normal, texCoord};
+ * src/bvh_interface.h:14-23) in gather order (mesh order, then triangle order; src/bvh.cpp:63-74). */
+int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out);
+void rt_bvh_destroy(rt_bvh* bvh);
+/* BVHInterface::nodes() / primitives() / numLevels() / numLeaves() (src/bvh_interface.h:64-71).
+ * Nodes are 32 bytes (src/bvh_interface.h:28-54), index 1 is the reference's unused dummy; primitives
+ * are stored twice per leaf exactly as the reference's build leaves them (src/bvh.cpp:387-392, 458). */
+uint32_t rt_bvh_num_nodes(const rt_bvh* bvh);
+uint32_t rt_bvh_num_primitives(const rt_bvh* bvh);
+uint32_t rt_bvh_num_levels(const rt_bvh* bvh);
+uint32_t rt_bvh_num_leaves(const rt_bvh* bvh);
+const void* rt_bvh_nodes(const rt_bvh* bvh);
+const void* rt_bvh_primitives(const rt_bvh* bvh);
+/* Gather-order index of each stored primitive (canonical triangle id; no reference counterpart -
+ * the reference identifies triangles only by position in the doubled array). */
+const uint32_t* rt_bvh_primitive_ids(const rt_bvh* bvh);
+
+/* Trackball(fovy, lookAt, dist, rotX, rotY) + position() + quat(eulerAngles)
+ * (framework/src/trackball.cpp:23-31, 71-74; src/main.cpp:519-520).  Angles in degrees as in
+ * CameraConfig (src/config.h:18-23); aspect = width / height (framework/src/window.cpp:413-418). */
+int rt_camera_from_trackball(float fovDegrees, float distance, const float lookAt[3], const float rotationDegrees[3],
+                             float aspect, rt_camera* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device side
+ * ------------------------------------------------------------------------------------------- */
+
+/* Number of visible GPUs / select the device used by later calls of this thread. */
+int rt_device_count(int* count);
+int rt_set_device(int device);
+
+/* Flatten + upload, once per scene.  Takes what `const BVHInterface&` and `const Scene&` give the
+ * reference's renderImage (src/render.h:34): bvh.nodes() (nNodes x 32 B), bvh.primitives()
+ * (nPrims x 100 B), per-mesh materials in mesh order as 8 floats {kd3, ks3, shininess, transparency}
+ * (framework/include/framework/mesh.h:22-34, textures are not carried), lights as 22 floats
+ * {type: 0 point / 1 segment / 2 parallelogram, then the struct's floats, src/common.h:45-60},
+ * spheres as 12 floats {center3, radius, kd3, ks3, shininess, transparency} (src/common.h:39-43).
+ * primIds (optional, nPrims) = canonical id reported for each stored primitive; null = its index.
+ * The tree is walked from node 0; unreachable nodes (the dummy) and the dead first copy of each
+ * leaf's primitives are dropped.  Everything is copied; the caller may free its arrays. */
+int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, const uint32_t* primIds,
+                    const float* materials8, uint32_t nMaterials, const float* lights22, uint32_t nLights,
+                    const float* spheres12, uint32_t nSpheres, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* The per-pixel loop of renderImage (src/render.cpp:27-44) for the rows in `region`:
+ * camera ray, renderRays(state, rays, startDepth) (src/recursive.cpp:10-83), Screen::setPixel.
+ * d_rgb: DEVICE pointer, W*H*3 floats in Screen order, index (H-1-y)*W + x (src/screen.cpp:36-42).
+ * d_primId / d_primT: optional DEVICE pointers (W*H, pixel order y*W + x) receiving the primary
+ * ray's canonical triangle id (0xffffffff = miss, 0xfffffffe = sphere) and t.
+ * startDepth is the rayDepth the reference passes to renderRays (0 = full depth 6; B bounces = 6-B).
+ * stream: a hipStream_t (null = default stream).  Asynchronous; rt_stats are valid after rt_sync. */
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height,
+              int startDepth, const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId,
+              float* d_primT, void* stream);
+
+/* postprocessImageWithBloom (src/extra.cpp:330-416) in place on a DEVICE Screen-order image.
+ * d_scratch: DEVICE buffer of at least rt_bloom_scratch_bytes(W,H) bytes.  With a region, only that
+ * region's rows are written (all rows of the input must hold the pre-bloom frame). */
+size_t rt_bloom_scratch_bytes(int width, int height);
+int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t filterSize, float threshold,
+             float intensity, const rt_region* region, void* stream);
+
+/* Wait for the work queued on `stream` by the calls above and fetch the scene's ray counters. */
+int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);
+
+/* renderImage (src/render.cpp:19-51) for host callers: render + optional bloom + copy back.
+ * rgb: HOST W*H*3 floats = Screen::pixels() (src/screen.h:25-26).  primId / primT: optional HOST
+ * W*H arrays.  Multi-sample, depth-of-field and motion-blur drivers are not part of this path. */
+int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height,
+                    int startDepth, uint32_t flags, float* rgb, uint32_t* primId, float* primT, rt_stats* stats);
+
+/* BVHInterface::intersect (src/bvh_interface.h:61) for a batch of rays on the GPU.
+ * rays: HOST n x 7 floats {origin3, direction3, t}; t is updated in place.
+ * hits: HOST n x 12 dwords {normal3, barycentric3, texCoord2 (floats), primId, meshID, hit(0/1), 0}. */
+int rt_intersect(rt_scene* scene, const rt_features* features, float* rays, uint32_t nRays, void* hits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,362 @@
+// Host side of librt_amd.so: BVH construction in the reference's layout, flattening into the GPU
+// layout, camera set-up.  Pure CPU code; runs once per scene, never per ray.
+#include "rt_types.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+
+namespace rt {
+
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH build: median split on the longest axis, leaves of at most 4 triangles
+// (reference src/bvh.cpp:48-95, 111-214, 381-512).
+//
+// The reference sorts 100-byte primitives with a comparator that recomputes both centroids; here
+// each level sorts 8-byte {key, index} records instead.  std::sort's sequence of comparisons and
+// moves depends only on the comparator's answers, which are the same floats, so the resulting
+// permutation - including the order among equal keys, which std::sort leaves unspecified but
+// deterministic - is the one the reference's build produces with the same standard library.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Builder {
+    const RefPrimitive* in;
+    std::vector<vec3> lo, hi, centroid; // per input primitive
+    std::vector<uint32_t> order;        // working permutation of input indices
+    std::vector<std::pair<float, uint32_t>> keys;
+    rt_bvh* out;
+
+    void emitLeafCopy(const uint32_t* idx, size_t n)
+    {
+        for (size_t i = 0; i < n; i++) {
+            out->prims.push_back(in[idx[i]]);
+            out->primIds.push_back(idx[i]);
+        }
+    }
+
+    void build(uint32_t* idx, size_t n, uint32_t nodeIndex)
+    {
+        // computeSpanAABB (src/bvh.cpp:125-137); an empty span keeps the default box [0,1]^3
+        RefNode node;
+        if (n < 1) {
+            node.lower[0] = node.lower[1] = node.lower[2] = 0.0f;
+            node.upper[0] = node.upper[1] = node.upper[2] = 1.0f;
+        } else {
+            vec3 lower = splat(FLT_MAX), upper = splat(-FLT_MAX);
+            for (size_t i = 0; i < n; i++) {
+                lower = gmin(lower, lo[idx[i]]);
+                upper = gmax(upper, hi[idx[i]]);
+            }
+            node.lower[0] = lower.x, node.lower[1] = lower.y, node.lower[2] = lower.z;
+            node.upper[0] = upper.x, node.upper[1] = upper.y, node.upper[2] = upper.z;
+        }
+        if (n <= 4) {
+            // The reference appends the leaf's primitives, records the offset AFTER that append, then
+            // appends them again (src/bvh.cpp:387-392, 458): primitives() holds every leaf twice and
+            // the recorded offset addresses the second copy.  Kept so nodes()/primitives() read the same.
+            emitLeafCopy(idx, n);
+            node.data[0] = uint32_t(out->prims.size()) | kLeafBit;
+            node.data[1] = uint32_t(n);
+            out->nodes[nodeIndex] = node;
+            emitLeafCopy(idx, n);
+            return;
+        }
+        // computeAABBLongestAxis (src/bvh.cpp:160-169): ties go to the lower axis index
+        const float ax = fabsf(node.upper[0] - node.lower[0]), ay = fabsf(node.upper[1] - node.lower[1]),
+                    az = fabsf(node.upper[2] - node.lower[2]);
+        const int axis = (ax >= ay && ax >= az) ? 0 : ((ay >= ax && ay >= az) ? 1 : 2);
+        // splitPrimitivesByMedian (src/bvh.cpp:181-214)
+        keys.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const vec3 c = centroid[idx[i]];
+            keys[i] = { axis == 0 ? c.x : (axis == 1 ? c.y : c.z), idx[i] };
+        }
+        std::sort(keys.begin(), keys.end(),
+                  [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
+        for (size_t i = 0; i < n; i++) idx[i] = keys[i].second;
+        const size_t split = (n + 1) / 2;
+        const uint32_t left = uint32_t(out->nodes.size());
+        out->nodes.emplace_back();
+        const uint32_t right = uint32_t(out->nodes.size());
+        out->nodes.emplace_back();
+        node.data[0] = left;
+        node.data[1] = right;
+        out->nodes[nodeIndex] = node;
+        build(idx, split, left);
+        build(idx + split, n - split, right);
+    }
+};
+
+void countLevelsAndLeaves(rt_bvh& b) // buildNumLevels / buildNumLeaves (src/bvh.cpp:517-577)
+{
+    std::vector<uint32_t> level { 0u }, next;
+    uint32_t levels = 0, leaves = 0;
+    while (!level.empty()) {
+        next.clear();
+        for (uint32_t i : level) {
+            const RefNode& n = b.nodes[i];
+            if (n.data[0] & kLeafBit) leaves++;
+            else {
+                next.push_back(n.data[0]);
+                next.push_back(n.data[1]);
+            }
+        }
+        levels++;
+        level.swap(next);
+    }
+    b.numLevels = levels;
+    b.numLeaves = leaves;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Flattening: reference nodes()/primitives() -> NodePair / TriPlane / TriEdges / TriAttr
+// ---------------------------------------------------------------------------------------------
+static void precomputeTriangle(const RefPrimitive& p, uint32_t primId, TriPlane& pl, TriEdges& ed, TriAttr& at)
+{
+    const vec3 v0 = load3(p.v0.position), v1 = load3(p.v1.position), v2 = load3(p.v2.position);
+    // trianglePlane of the reference's intersect archive == the geometric normal of updateHitInfo
+    vec3 n = cross(v1 - v0, v2 - v0);
+    n = n * (1.0f / sqrtf(dot(n, n)));
+    pl.n[0] = n.x, pl.n[1] = n.y, pl.n[2] = n.z;
+    pl.D = dot(v0, n);
+    // pointInTriangle edge vectors
+    const vec3 c0 = cross(v2 - v0, n), c1 = cross(v0 - v1, n), c2 = cross(v1 - v2, n);
+    ed.v0[0] = v0.x, ed.v0[1] = v0.y, ed.v0[2] = v0.z, ed.c0x = c0.x;
+    ed.c0y = c0.y, ed.c0z = c0.z, ed.v1x = v1.x, ed.v1y = v1.y;
+    ed.v1z = v1.z, ed.c1[0] = c1.x, ed.c1[1] = c1.y, ed.c1[2] = c1.z;
+    ed.v2[0] = v2.x, ed.v2[1] = v2.y, ed.v2[2] = v2.z, ed.c2x = c2.x;
+    ed.c2y = c2.y, ed.c2z = c2.z, ed.pad[0] = ed.pad[1] = 0.0f;
+    // computeBarycentricCoord constants (src/interpolate.cpp:13-23)
+    const vec3 first = v1 - v0, second = v2 - v0;
+    at.primId = primId;
+    at.meshID = p.meshID;
+    at.d00 = dot(first, first);
+    at.d01 = dot(first, second);
+    at.d11 = dot(second, second);
+    at.denom = at.d00 * at.d11 - at.d01 * at.d01;
+    memcpy(at.n0, p.v0.normal, 12);
+    memcpy(at.n1, p.v1.normal, 12);
+    memcpy(at.n2, p.v2.normal, 12);
+    memcpy(at.uv0, p.v0.texCoord, 8);
+    memcpy(at.uv1, p.v1.texCoord, 8);
+    memcpy(at.uv2, p.v2.texCoord, 8);
+    at.pad[0] = at.pad[1] = at.pad[2] = 0.0f;
+}
+
+namespace {
+struct Flattener {
+    const RefNode* nodes;
+    uint32_t nNodes;
+    const RefPrimitive* prims;
+    uint32_t nPrims;
+    const uint32_t* primIds;
+    uint32_t nMaterials;
+    FlatScene& out;
+    char* msg;
+    size_t msgLen;
+    int status = RT_OK;
+    std::vector<uint8_t> seen;
+    std::vector<std::pair<uint32_t, uint32_t>> arrayPos; // (position in primitives(), compact index)
+
+    uint32_t fail(int code)
+    {
+        status = code;
+        return kLeafBit;
+    }
+    // Child reference for node i; lays out NodePairs in pre-order and triangles in left-to-right
+    // leaf order.  Recursion is bounded by the depth limit checked on entry.
+    uint32_t visit(uint32_t i, uint32_t depth)
+    {
+        if (status != RT_OK) return kLeafBit;
+        if (i >= nNodes) {
+            snprintf(msg, msgLen, "flatten: child index %u out of range (%u nodes)", i, nNodes);
+            return fail(RT_ERR_INVALID);
+        }
+        if (depth > uint32_t(kStackDepth)) {
+            snprintf(msg, msgLen, "flatten: tree deeper than %d levels (traversal stack limit)", kStackDepth);
+            return fail(RT_ERR_LIMIT);
+        }
+        if (seen[i]) {
+            snprintf(msg, msgLen, "flatten: node %u is reachable twice (not a tree)", i);
+            return fail(RT_ERR_INVALID);
+        }
+        seen[i] = 1;
+        if (depth > out.maxDepth) out.maxDepth = depth;
+        const RefNode& n = nodes[i];
+        if (n.data[0] & kLeafBit) {
+            const uint32_t off = n.data[0] & ~kLeafBit, cnt = n.data[1];
+            if (cnt > kMaxLeafCount) {
+                snprintf(msg, msgLen, "flatten: leaf %u holds %u primitives (limit %u)", i, cnt, kMaxLeafCount);
+                return fail(RT_ERR_LIMIT);
+            }
+            if (uint64_t(off) + cnt > nPrims || (cnt && !prims)) {
+                snprintf(msg, msgLen, "flatten: leaf %u range [%u,%u) exceeds %u primitives", i, off, off + cnt, nPrims);
+                return fail(RT_ERR_INVALID);
+            }
+            const uint32_t first = uint32_t(out.triPlane.size());
+            if (uint64_t(first) + cnt > kRefOffsetMask) {
+                snprintf(msg, msgLen, "flatten: more than %u triangles", kRefOffsetMask);
+                return fail(RT_ERR_LIMIT);
+            }
+            for (uint32_t k = 0; k < cnt; k++) {
+                const RefPrimitive& p = prims[off + k];
+                if (p.meshID >= nMaterials) {
+                    snprintf(msg, msgLen, "flatten: primitive %u has meshID %u but only %u materials", off + k, p.meshID, nMaterials);
+                    return fail(RT_ERR_INVALID);
+                }
+                TriPlane pl;
+                TriEdges ed;
+                TriAttr at;
+                precomputeTriangle(p, primIds ? primIds[off + k] : off + k, pl, ed, at);
+                arrayPos.push_back({ off + k, uint32_t(out.triPlane.size()) });
+                out.triPlane.push_back(pl);
+                out.triEdges.push_back(ed);
+                out.triAttr.push_back(at);
+            }
+            return kLeafBit | (cnt << kRefCountShift) | first;
+        }
+        const uint32_t l = n.data[0], r = n.data[1];
+        if (l >= nNodes || r >= nNodes) {
+            snprintf(msg, msgLen, "flatten: node %u has a child index out of range", i);
+            return fail(RT_ERR_INVALID);
+        }
+        const uint32_t pair = uint32_t(out.pairs.size());
+        out.pairs.emplace_back();
+        NodePair np;
+        memcpy(np.lo0, nodes[l].lower, 12);
+        memcpy(np.hi0, nodes[l].upper, 12);
+        memcpy(np.lo1, nodes[r].lower, 12);
+        memcpy(np.hi1, nodes[r].upper, 12);
+        np.pad0 = np.pad1 = 0;
+        np.ref0 = visit(l, depth + 1);
+        np.ref1 = visit(r, depth + 1);
+        out.pairs[pair] = np;
+        return pair;
+    }
+};
+} // namespace
+
+int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,
+            uint32_t nMaterials, FlatScene& out, const char** err)
+{
+    static thread_local char msg[256];
+    msg[0] = 0;
+    *err = msg;
+    if (!nodes || nNodes == 0) {
+        snprintf(msg, sizeof(msg), "flatten: empty node array");
+        return RT_ERR_INVALID;
+    }
+    out = FlatScene {};
+    Flattener f { nodes, nNodes, prims, nPrims, primIds, nMaterials, out, msg, sizeof(msg) };
+    f.seen.assign(nNodes, 0);
+    memcpy(out.rootLo, nodes[0].lower, 12);
+    memcpy(out.rootHi, nodes[0].upper, 12);
+    out.rootRef = f.visit(0, 1);
+    if (f.status != RT_OK) return f.status;
+    // Brute-force order (enableAccelStructure off, src/bvh.cpp:351-363) = primitives() array order.
+    std::sort(f.arrayPos.begin(), f.arrayPos.end());
+    out.bruteOrder.resize(f.arrayPos.size());
+    for (size_t i = 0; i < f.arrayPos.size(); i++) out.bruteOrder[i] = f.arrayPos[i].second;
+    return RT_OK;
+}
+
+} // namespace rt
+
+// =============================================================================================
+// C ABI, host side
+// =============================================================================================
+using namespace rt;
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error; }
+
+int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out)
+{
+    if (!out || (nPrims && !prims)) {
+        set_error("rt_bvh_build: null argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    rt_bvh* b = new (std::nothrow) rt_bvh();
+    if (!b) {
+        set_error("rt_bvh_build: out of memory");
+        return RT_ERR_NOMEM;
+    }
+    Builder bl;
+    bl.in = static_cast<const RefPrimitive*>(prims);
+    bl.out = b;
+    bl.lo.resize(nPrims);
+    bl.hi.resize(nPrims);
+    bl.centroid.resize(nPrims);
+    bl.order.resize(nPrims);
+    for (uint32_t i = 0; i < nPrims; i++) {
+        const RefPrimitive& p = bl.in[i];
+        const vec3 a = load3(p.v0.position), c = load3(p.v1.position), d = load3(p.v2.position);
+        bl.lo[i] = gmin(gmin(a, c), d); // computePrimitiveAABB operand order (src/bvh.cpp:111-118)
+        bl.hi[i] = gmax(gmax(a, c), d);
+        bl.centroid[i] = (a + c + d) / 3.0f; // computePrimitiveCentroid (src/bvh.cpp:144-152)
+        bl.order[i] = i;
+    }
+    b->prims.reserve(size_t(nPrims) * 2);
+    b->primIds.reserve(size_t(nPrims) * 2);
+    b->nodes.reserve(size_t(nPrims) + 2);
+    b->nodes.emplace_back(); // root
+    b->nodes.emplace_back(); // the reference's dummy second node (src/bvh.cpp:82): default box, zero data
+    RefNode& dummy = b->nodes[1];
+    dummy.lower[0] = dummy.lower[1] = dummy.lower[2] = 0.0f;
+    dummy.upper[0] = dummy.upper[1] = dummy.upper[2] = 1.0f;
+    dummy.data[0] = dummy.data[1] = 0;
+    bl.build(bl.order.data(), nPrims, 0);
+    countLevelsAndLeaves(*b);
+    *out = b;
+    return RT_OK;
+}
+void rt_bvh_destroy(rt_bvh* bvh) { delete bvh; }
+uint32_t rt_bvh_num_nodes(const rt_bvh* b) { return b ? uint32_t(b->nodes.size()) : 0; }
+uint32_t rt_bvh_num_primitives(const rt_bvh* b) { return b ? uint32_t(b->prims.size()) : 0; }
+uint32_t rt_bvh_num_levels(const rt_bvh* b) { return b ? b->numLevels : 0; }
+uint32_t rt_bvh_num_leaves(const rt_bvh* b) { return b ? b->numLeaves : 0; }
+const void* rt_bvh_nodes(const rt_bvh* b) { return b ? b->nodes.data() : nullptr; }
+const void* rt_bvh_primitives(const rt_bvh* b) { return b ? b->prims.data() : nullptr; }
+const uint32_t* rt_bvh_primitive_ids(const rt_bvh* b) { return b ? b->primIds.data() : nullptr; }
+
+int rt_camera_from_trackball(float fovDegrees, float distance, const float lookAt[3], const float rotationDegrees[3],
+                             float aspect, rt_camera* out)
+{
+    if (!lookAt || !rotationDegrees || !out) {
+        set_error("rt_camera_from_trackball: null argument");
+        return RT_ERR_INVALID;
+    }
+    const float kRad = static_cast<float>(0.01745329251994329576923690768489); // glm::radians
+    const float ex = rotationDegrees[0] * kRad, ey = rotationDegrees[1] * kRad, ez = rotationDegrees[2] * kRad;
+    const float fovy = fovDegrees * kRad;
+    // glm::quat(eulerAngles), type_quat.inl:208-217
+    const float cx = cosf(ex * 0.5f), cy = cosf(ey * 0.5f), cz = cosf(ez * 0.5f);
+    const float sx = sinf(ex * 0.5f), sy = sinf(ey * 0.5f), sz = sinf(ez * 0.5f);
+    out->quat[0] = cx * cy * cz + sx * sy * sz;
+    out->quat[1] = sx * cy * cz - cx * sy * sz;
+    out->quat[2] = cx * sy * cz + sx * cy * sz;
+    out->quat[3] = cx * cy * sz - sx * sy * cz;
+    const vec3 pos = load3(lookAt) + quat_rotate(out->quat, make3(0.0f, 0.0f, -distance));
+    out->position[0] = pos.x, out->position[1] = pos.y, out->position[2] = pos.z;
+    out->halfHeight = tanf(fovy / 2.0f);
+    out->halfWidth = aspect * out->halfHeight;
+    return RT_OK;
+}
+
+} // extern "C"

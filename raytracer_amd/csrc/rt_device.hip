@@ -1,0 +1,1265 @@
+// Device side of librt_amd.so for gfx950 (MI355X): BVH traversal, ray/box and ray/triangle tests,
+// the recursive radiance estimate (lights, shadow rays, specular and glossy reflections) and the
+// bloom post-process, plus the C ABI around them.
+//
+// Arithmetic contract: IEEE fp32, no contraction (-ffp-contract=off), correctly rounded division
+// and square root, denormals kept.  Expression order follows the reference expression cited at
+// each function because float ties decide which triangle a ray reports.
+#include "rt_types.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace rt;
+
+// =============================================================================================
+// Host-side scene object
+// =============================================================================================
+struct rt_scene {
+    int device = 0;
+    SceneView view {};
+    void* d_blob = nullptr; // one allocation holding every scene array
+    size_t blobBytes = 0;
+    unsigned long long* d_stats = nullptr; // 8 counters
+    uint32_t* d_work = nullptr;            // work-fetch counter
+    // lazily sized device buffers for rt_render_image
+    float* d_rgb = nullptr;
+    float* d_scratch = nullptr;
+    uint32_t* d_primId = nullptr;
+    float* d_primT = nullptr;
+    size_t fbPixels = 0;
+    bool hasTextures = false;
+    uint32_t treeDepth = 0;
+    int numCUs = 256;
+};
+
+#define RT_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            rt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+constexpr int kBlock = 256;     // 4 waves per workgroup
+constexpr int kFrameFloats = 20; // per recursion level saved state
+constexpr float kFltMin = 1.17549435e-38f;
+
+enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_COUNT = 8 };
+
+struct RenderParams {
+    SceneView S;
+    rt_camera cam;
+    rt_features F;
+    int W, H, startDepth;
+    int tilesX, myTileRows, stripeTileRows, rank, world;
+    uint32_t nWork;
+    float* rgb;
+    uint32_t* primId;
+    float* primT;
+    unsigned long long* stats;
+    uint32_t* work;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Sampler (reference src/sampler.h:13-46)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sampler_next(uint32_t& state)
+{
+    state = state * 747796405u + 2891336453u;
+    uint32_t v = state;
+    v ^= v >> ((v >> 28u) + 4u);
+    v *= 277803737u;
+    v ^= v >> 22u;
+    return static_cast<float>(v) / 4294967295.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray / box: the slab test of the reference's intersect archive (symbol
+// intersectRayWithShape(AxisAlignedBox const&, Ray&), declared src/intersect.h:16).
+// Returns the reported distance in tOut: the entry distance, or the EXIT distance when the origin is
+// inside the box; `outside` tells which.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool box_test(const float lox, const float loy, const float loz, const float hix, const float hiy,
+                                         const float hiz, const vec3 o, const vec3 d, const float tmax, float& tOut, bool& outside)
+{
+    const float tUx = (d.x == 0.0f) ? FLT_MAX : (hix - o.x) / d.x;
+    const float tUy = (d.y == 0.0f) ? FLT_MAX : (hiy - o.y) / d.y;
+    const float tUz = (d.z == 0.0f) ? FLT_MAX : (hiz - o.z) / d.z;
+    const float tLx = (d.x == 0.0f) ? kFltMin : (lox - o.x) / d.x;
+    const float tLy = (d.y == 0.0f) ? kFltMin : (loy - o.y) / d.y;
+    const float tLz = (d.z == 0.0f) ? kFltMin : (loz - o.z) / d.z;
+    float tin = sse_max(sse_min(tUz, tLz), sse_max(sse_min(tUy, tLy), sse_min(tUx, tLx)));
+    float tout = sse_min(sse_max(tUz, tLz), sse_min(sse_max(tUy, tLy), sse_max(tUx, tLx)));
+    outside = true;
+    if (0.0f > tin) {
+        if (!(tout > 0.0f)) return false;
+        tin = tout;
+        tout = FLT_MAX;
+        outside = false;
+    }
+    if (tin > tout) return false;
+    if (0.0f > tin) return false;
+    if (tin > tmax) return false;
+    tOut = tin;
+    return true;
+}
+
+struct TraceCounters {
+    uint32_t nodePairs, triTests, overflow;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Ray / triangle with hoisted per-triangle constants (archive symbols trianglePlane,
+// intersectRayWithTriangle, pointInTriangle; declared src/intersect.h:5-12).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_test(const SceneView& S, const uint32_t i, const vec3 o, const vec3 d, float& t, uint32_t& tri)
+{
+    const float4 pl = reinterpret_cast<const float4*>(S.triPlane)[i];
+    const vec3 n = make3(pl.x, pl.y, pl.z);
+    const float tt = (pl.w - dot(o, n)) / dot(d, n);
+    if (!(tt >= 0.0f)) return;
+    if (!(t >= tt)) return; // equal distance accepted: the later candidate wins the tie
+    const float4* e = reinterpret_cast<const float4*>(S.triEdges + i);
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+    const vec3 p = d * tt + o;
+    const vec3 v0 = make3(e0.x, e0.y, e0.z), c0 = make3(e0.w, e1.x, e1.y);
+    if (!(dot(c0, p - v0) >= 0.0f)) return;
+    const vec3 v1 = make3(e1.z, e1.w, e2.x), c1 = make3(e2.y, e2.z, e2.w);
+    if (!(dot(c1, p - v1) >= 0.0f)) return;
+    const vec3 v2 = make3(e3.x, e3.y, e3.z), c2 = make3(e3.w, e4.x, e4.y);
+    if (!(dot(c2, p - v2) >= 0.0f)) return;
+    t = tt;
+    tri = i;
+}
+
+// Ray / sphere (archive symbol intersectRayWithShape(Sphere const&, Ray&, HitInfo&), src/intersect.h:14)
+__device__ __forceinline__ bool sphere_test(const GpuSphere& sp, const vec3 o, const vec3 d, float& t)
+{
+    const vec3 L = o - load3(sp.center);
+    const float h = dot(d, L);
+    const float b = h + h;
+    const float cc = dot(L, L) - sp.radius * sp.radius;
+    const float disc = b * b - 4.0f * cc;
+    if (disc < 0.0f) return false;
+    float t0, t1;
+    if (disc == 0.0f) {
+        t0 = t1 = 0.5f * (-b);
+    } else {
+        const float s = sqrtf(disc);
+        t0 = (-b - s) * 0.5f;
+        t1 = (s - b) * 0.5f;
+    }
+    float tt = FLT_MAX;
+    if (t0 >= 0.0f && t0 < tt) tt = t0;
+    if (t1 >= 0.0f && t1 < tt) tt = t1;
+    if (tt < 0.0f || tt >= t) return false;
+    t = tt;
+    return true;
+}
+
+constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
+
+// ---------------------------------------------------------------------------------------------
+// Closest hit (reference intersectRayWithBVH, src/bvh.cpp:235-370).  Near child first, ties to the
+// right child, leaves tested in storage order, `t >= candidate` accepted.  With CULL a child box
+// whose entry lies beyond the closest hit so far is skipped (the reference visits it and finds
+// nothing closer); without CULL the visit order is the reference's exactly.
+// `stack` points at this lane's column of the LDS stack (stride kBlock).
+// ---------------------------------------------------------------------------------------------
+template <bool CULL, bool COUNT>
+__device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, const vec3 o, const vec3 d, float& t, uint32_t& tri,
+                                      uint32_t* stack, TraceCounters& tc)
+{
+    tri = kNoHit;
+    if (useBvh) {
+        float tr;
+        bool outside;
+        // root box against the ray's own t; a miss returns before the sphere loop (src/bvh.cpp:264-268)
+        if (!box_test(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], o, d, t, tr, outside)) return;
+        int sp = 0;
+        uint32_t cur = S.rootRef;
+        for (;;) {
+            if (!(cur & kLeafBit)) {
+                const float4* q = reinterpret_cast<const float4*>(S.pairs + cur);
+                const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+                if (COUNT) tc.nodePairs++;
+                float tl = FLT_MAX, trr = FLT_MAX;
+                bool outL, outR;
+                bool hl = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, d, FLT_MAX, tl, outL);
+                bool hr = box_test(c.x, c.y, c.z, c.w, e.x, e.y, o, d, FLT_MAX, trr, outR);
+                const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
+                const bool leftNear = tl < trr; // equal distances: right first (src/bvh.cpp:301-310)
+                if (CULL) {
+                    hl = hl && !(outL && tl > t);
+                    hr = hr && !(outR && trr > t);
+                }
+                if (hl && hr) {
+                    const uint32_t nearRef = leftNear ? ref0 : ref1, farRef = leftNear ? ref1 : ref0;
+                    if (sp < kStackDepth) stack[sp * kBlock] = farRef;
+                    else tc.overflow++;
+                    sp++;
+                    cur = nearRef;
+                    continue;
+                } else if (hl) {
+                    cur = ref0;
+                    continue;
+                } else if (hr) {
+                    cur = ref1;
+                    continue;
+                }
+            } else {
+                const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    if (COUNT) tc.triTests++;
+                    tri_test(S, first + k, o, d, t, tri);
+                }
+            }
+            if (sp == 0) break;
+            sp--;
+            cur = (sp < kStackDepth) ? stack[sp * kBlock] : (kLeafBit); // overflowed entries are dropped (counted)
+        }
+    } else {
+        // enableAccelStructure off (src/bvh.cpp:351-363): every stored triangle, array order
+        for (uint32_t k = 0; k < S.nTris; k++) {
+            if (COUNT) tc.triTests++;
+            tri_test(S, S.bruteOrder[k], o, d, t, tri);
+        }
+    }
+    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+        if (sphere_test(S.spheres[s], o, d, t)) tri = kSphereBase + s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hit record (updateHitInfo src/bvh.cpp:18-44, computeBarycentricCoord / interpolateNormal
+// src/interpolate.cpp:13-51).
+// ---------------------------------------------------------------------------------------------
+struct Hit {
+    vec3 normal;
+    vec3 bary;
+    vec2 uv;
+    uint32_t mesh;   // material index (meshID), or sphere index with isSphere
+    uint32_t primId; // canonical id
+    bool isSphere;
+};
+
+__device__ __forceinline__ void fill_hit(const SceneView& S, const rt_features& F, const uint32_t tri, const vec3 o, const vec3 d,
+                                         const float t, Hit& h)
+{
+    if (tri >= kSphereBase) {
+        const GpuSphere& sp = S.spheres[tri - kSphereBase];
+        h.normal = normalize((d * t + o) - load3(sp.center));
+        h.bary = splat(0.0f);
+        h.uv = vec2 { 0.0f, 0.0f };
+        h.mesh = tri - kSphereBase;
+        h.primId = 0xfffffffeu;
+        h.isSphere = true;
+        return;
+    }
+    h.isSphere = false;
+    const float4 pl = reinterpret_cast<const float4*>(S.triPlane)[tri];
+    const vec3 n = make3(pl.x, pl.y, pl.z);
+    const float4* e = reinterpret_cast<const float4*>(S.triEdges + tri);
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+    const vec3 v0 = make3(e0.x, e0.y, e0.z), v1 = make3(e1.z, e1.w, e2.x), v2 = make3(e3.x, e3.y, e3.z);
+    const float4* aq = reinterpret_cast<const float4*>(S.triAttr + tri);
+    const float4 a0 = aq[0], a1 = aq[1], a2 = aq[2], a3 = aq[3], a4 = aq[4];
+    h.primId = __float_as_uint(a0.x);
+    h.mesh = __float_as_uint(a0.y);
+    const float d00 = a0.z, d01 = a0.w, d11 = a1.x, denom = a1.y;
+    const vec3 p = o + t * d;
+    const vec3 first = v1 - v0, second = v2 - v0, point = p - v0;
+    const float d0p = dot(first, point), d1p = dot(second, point);
+    const float beta = (d11 * d0p - d01 * d1p) / denom;
+    const float gamma = (d00 * d1p - d01 * d0p) / denom;
+    h.bary = make3(1.f - beta - gamma, beta, gamma);
+    h.normal = n;
+    if (F.enableNormalInterp) {
+        const vec3 n0 = make3(a1.z, a1.w, a2.x), n1 = make3(a2.y, a2.z, a2.w), n2 = make3(a3.x, a3.y, a3.z);
+        h.normal = h.bary.x * n0 + h.bary.y * n1 + h.bary.z * n2;
+    }
+    if (F.enableTextureMapping) {
+        const float4 a5 = aq[5];
+        const vec2 t0 { a3.w, a4.x }, t1 { a4.y, a4.z }, t2 { a4.w, a5.x };
+        h.uv = h.bary.x * t0 + h.bary.y * t1 + h.bary.z * t2;
+    } else {
+        h.uv = vec2 { 0.0f, 0.0f };
+    }
+    if (dot(d, n) > 0.0f) h.normal = -h.normal;
+}
+
+struct Mat {
+    vec3 kd, ks;
+    float shininess, transparency;
+};
+__device__ __forceinline__ Mat load_material(const SceneView& S, const uint32_t mesh, const bool isSphere)
+{
+    Mat m;
+    if (isSphere) {
+        const GpuSphere& sp = S.spheres[mesh];
+        m.kd = load3(sp.kd);
+        m.ks = load3(sp.ks);
+        m.shininess = sp.shininess;
+        m.transparency = sp.transparency;
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(S.materials + mesh);
+        const float4 a = q[0], b = q[1];
+        m.kd = make3(a.x, a.y, a.z);
+        m.shininess = a.w;
+        m.ks = make3(b.x, b.y, b.z);
+        m.transparency = b.w;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shading models (src/shading.cpp:29-233); kd is the material colour (textures not carried)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ vec3 lambert(const vec3 lightDirection, const vec3 lightColor, const vec3 normal, const Mat& m)
+{
+    const vec3 l = normalize(lightDirection), n = normalize(normal);
+    const float dt = dot(l, n);
+    if (dt <= 0) return splat(0.0f);
+    return m.kd * lightColor * dt;
+}
+__device__ vec3 gradient_sample(const float ti) // LinearGradient::sample over the hard-coded gradient (src/shading.cpp:32-40,185-211)
+{
+    const float ts[5] = { 0.1f, 0.22f, 0.5f, 0.78f, 0.9f };
+    const vec3 cs[5] = { make3(215.f / 256.f, 210.f / 256.f, 203.f / 256.f), make3(250.f / 256.f, 250.f / 256.f, 240.f / 256.f),
+                         make3(145.f / 256.f, 170.f / 256.f, 175.f / 256.f), make3(255.f / 256.f, 250.f / 256.f, 205.f / 256.f),
+                         make3(170.f / 256.f, 170.f / 256.f, 170.f / 256.f) };
+    if (ts[0] > ti) return cs[0];
+    for (int i = 0; i < 4; i++) {
+        if (fabsf(ts[i] - ti) <= 1e-6f) return cs[i];
+        if (ts[i] < ti && ts[i + 1] > ti) {
+            const float alpha = (ti - ts[i]) / (ts[i + 1] - ts[i]);
+            return (1.0f - alpha) * cs[i] + alpha * cs[i + 1];
+        }
+    }
+    return cs[4];
+}
+__device__ vec3 shade(const rt_features& F, const vec3 cameraDirection, const vec3 lightDirection, const vec3 lightColor,
+                      const vec3 normal, const Mat& m)
+{
+    if (!F.enableShading) return lightColor * m.kd;
+    switch (F.shadingModel) {
+    case 0: return lambert(lightDirection, lightColor, normal, m);
+    case 1: { // computePhongModel, src/shading.cpp:92-123
+        const vec3 diffuse = lambert(lightDirection, lightColor, normal, m);
+        const vec3 d = normalize(-lightDirection), n = normalize(normal);
+        const float dt = dot(-d, n);
+        if (dt <= 0) return diffuse;
+        const vec3 v = normalize(cameraDirection);
+        const vec3 r = normalize(d - 2.0f * dot(d, n) * n);
+        const float VdotR = dot(v, r);
+        if (VdotR <= 0) return diffuse;
+        const float pw = powf(VdotR, m.shininess);
+        return diffuse + pw * m.ks * lightColor;
+    }
+    case 2: { // computeBlinnPhongModel, src/shading.cpp:140-169
+        const vec3 diffuse = lambert(lightDirection, lightColor, normal, m);
+        const vec3 d = normalize(lightDirection), n = normalize(normal);
+        const float dt = dot(n, d);
+        if (dt <= 0) return diffuse;
+        const vec3 hv = normalize(d + cameraDirection);
+        const float NdotH = dot(n, hv);
+        if (NdotH <= 0) return diffuse;
+        const float pw = powf(NdotH, m.shininess);
+        return diffuse + pw * m.ks * lightColor;
+    }
+    default: { // computeLinearGradientModel, src/shading.cpp:228-233
+        const float c = dot(normalize(lightDirection), normalize(normal));
+        return lightColor * gradient_sample(c);
+    }
+    }
+}
+
+// constructOrthonormalBasis (src/extra.cpp:418-441)
+__device__ __forceinline__ void ortho_basis(const vec3 r, vec3& w, vec3& u, vec3& v)
+{
+    w = normalize(r);
+    const float ax = fabsf(w.x), ay = fabsf(w.y), az = fabsf(w.z);
+    vec3 t;
+    if (ax < ay && ax < az) t = make3(1.0f, w.y, w.z);
+    else if (ay < ax && ay < az) t = make3(w.x, 1.0f, w.z);
+    else t = make3(w.x, w.y, 1.0f);
+    u = normalize(cross(t, w));
+    v = cross(w, u);
+}
+
+// Trackball::generateRay (framework/src/trackball.cpp:101-110) with the quaternion precomputed
+__device__ __forceinline__ void camera_ray(const rt_camera& cam, const float ndcX, const float ndcY, vec3& o, vec3& d)
+{
+    const vec3 cs = normalize(make3(-ndcX * cam.halfWidth, ndcY * cam.halfHeight, 1.0f));
+    o = load3(cam.position);
+    d = quat_rotate(cam.quat, cs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The render kernel: one lane = one pixel at a time, pixels fetched from a shared counter.
+//
+// renderRay's recursion (src/recursive.cpp:25-83) is run as an explicit depth-first state machine
+// so that each pixel's sampler is consumed in exactly the reference's order (glossy samples draw
+// two numbers each, in recursion order, src/extra.cpp:489-505).  Every lane funnels all of its
+// closest-hit queries - primary, shadow, reflection - through the single trace() call in the loop
+// body, so a wave keeps traversing together whatever mix of ray kinds its lanes hold.
+// ---------------------------------------------------------------------------------------------
+enum LaneState : int { ST_NEW = 0, ST_EXIT, ST_TRACE, ST_HIT_RAD, ST_HIT_SHD, ST_LIGHTS, ST_SPAWN, ST_GLOSSY_NEXT, ST_RETURN };
+enum ChildKind : int { CK_SPEC = 0, CK_GLOSSY = 1 };
+
+template <bool CULL, bool COUNT, bool PERSISTENT>
+__global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
+{
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    uint32_t* const stack = s_stack + threadIdx.x;
+    const SceneView& S = P.S;
+    const rt_features& F = P.F;
+    const int lane = threadIdx.x & 63;
+
+    // saved state of the callers of the ray being evaluated, indexed by their rayDepth
+    float frames[RT_MAX_RAY_DEPTH * kFrameFloats];
+
+    // pixel
+    uint32_t px = 0, py = 0, smp = 0, seed = 0;
+    uint32_t sampleIdx = 0, nPixelRays = 1;
+    vec3 Lsum = splat(0.0f);
+    // ray being traced
+    vec3 to = splat(0.0f), td = splat(0.0f);
+    float tt = 0.0f;
+    uint32_t ttri = kNoHit;
+    bool traceIsShadow = false;
+    // radiance ray + hit under evaluation
+    int depth = 0;
+    vec3 ro = splat(0.0f), rd = splat(0.0f);
+    float rt = 0.0f;
+    vec3 hn = splat(0.0f);
+    uint32_t hmesh = 0;
+    bool hsphere = false;
+    vec3 Lo = splat(0.0f);
+    // light loop
+    uint32_t lightIdx = 0, lightSample = 0;
+    vec3 areaAcc = splat(0.0f), lpos = splat(0.0f), lcol = splat(0.0f);
+    vec3 ret = splat(0.0f);
+    // counters
+    uint32_t cPrimary = 0, cShadow = 0, cSecondary = 0, cPixels = 0;
+    TraceCounters tc { 0, 0, 0 };
+
+    int state = ST_NEW;
+    uint32_t staticNext = blockIdx.x * kBlock + threadIdx.x;
+
+    for (;;) {
+        // ---- pixel fetch (wave-convergent) ----
+        if (__ballot(state == ST_NEW) != 0ull) {
+            uint32_t w = 0xffffffffu;
+            if (PERSISTENT) {
+                const bool need = (state == ST_NEW);
+                const unsigned long long mask = __ballot(need);
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(P.work, (uint32_t)__popcll(mask));
+                base = __shfl(base, leader);
+                if (need) w = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            } else if (state == ST_NEW) {
+                w = staticNext;
+                staticNext += gridDim.x * kBlock;
+            }
+            if (state == ST_NEW) {
+                if (w >= P.nWork) {
+                    state = ST_EXIT;
+                } else {
+                    const uint32_t tile = w >> 6, l = w & 63;
+                    const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
+                    const uint32_t blk = m / P.stripeTileRows, r = m - blk * P.stripeTileRows;
+                    const uint32_t ty = (blk * P.world + P.rank) * P.stripeTileRows + r;
+                    px = tx * 8 + (l & 7);
+                    py = ty * 8 + (l >> 3);
+                    if (px < (uint32_t)P.W && py < (uint32_t)P.H) {
+                        cPixels++;
+                        seed = static_cast<uint32_t>(P.H * (int)px + (int)py); // src/render.cpp:38
+                        smp = seed;
+                        sampleIdx = 0;
+                        Lsum = splat(0.0f);
+                        nPixelRays = 1;
+                        if (F.numPixelSamples > 1) { // generatePixelRays* draw every offset before tracing (src/render.cpp:82-123)
+                            if (F.enableJitteredSampling) {
+                                const uint32_t ns = (uint32_t)roundf(sqrtf((float)F.numPixelSamples));
+                                nPixelRays = ns * ns;
+                            } else {
+                                nPixelRays = F.numPixelSamples;
+                            }
+                            for (uint32_t k = 0; k < 2 * nPixelRays; k++) (void)sampler_next(smp);
+                        }
+                        state = ST_RETURN; // enters the per-pixel ray loop with nothing accumulated yet
+                        ret = splat(0.0f);
+                        depth = P.startDepth - 1; // sentinel: "return to pixel level"
+                        sampleIdx = 0xffffffffu;  // becomes 0 on the first pass through ST_RETURN
+                    }
+                }
+            }
+        }
+
+        // ---- advance every lane to its next query (or to NEW / EXIT) ----
+        while (state > ST_TRACE) {
+            switch (state) {
+            case ST_HIT_RAD: {
+                // renderRay after state.bvh.intersect (src/recursive.cpp:29-36)
+                if (ttri == kNoHit) {
+                    ret = splat(0.0f); // sampleEnvironmentMap with the map disabled (src/extra.cpp:577-579)
+                    state = ST_RETURN;
+                    break;
+                }
+                ro = to, rd = td, rt = tt;
+                Hit h;
+                fill_hit(S, F, ttri, ro, rd, rt, h);
+                hn = h.normal;
+                hmesh = h.mesh;
+                hsphere = h.isSphere;
+                if (depth == P.startDepth && sampleIdx == 0 && P.primId) P.primId[py * P.W + px] = h.primId;
+                if (depth == P.startDepth && sampleIdx == 0 && P.primT) P.primT[py * P.W + px] = rt;
+                Lo = splat(0.0f);
+                lightIdx = 0;
+                lightSample = 0;
+                areaAcc = splat(0.0f);
+                state = ST_LIGHTS;
+                break;
+            }
+            case ST_LIGHTS: {
+                // computeLightContribution (src/light.cpp:262-276), resumable at (lightIdx, lightSample)
+                if (lightIdx >= S.nLights) {
+                    state = ST_SPAWN;
+                    break;
+                }
+                const GpuLight& L = S.lights[lightIdx];
+                const int type = (int)L.type;
+                if (type != 0 && lightSample >= F.numShadowSamples) { // area light finished (src/light.cpp:185-194, 222-231)
+                    Lo = Lo + areaAcc;
+                    areaAcc = splat(0.0f);
+                    lightSample = 0;
+                    lightIdx++;
+                    break;
+                }
+                if (type == 0) {
+                    lpos = load3(L.f);
+                    lcol = load3(L.f + 3);
+                } else if (type == 1) { // sampleSegmentLight (src/light.cpp:25-29)
+                    const float s = sampler_next(smp);
+                    const vec3 e0 = load3(L.f), e1 = load3(L.f + 3), c0 = load3(L.f + 6), c1 = load3(L.f + 9);
+                    lpos = e0 + s * (e1 - e0);
+                    lcol = c0 + s * (c1 - c0);
+                } else { // sampleParallelogramLight (src/light.cpp:40-53)
+                    const float sx = sampler_next(smp);
+                    const float sy = sampler_next(smp);
+                    const vec3 v0 = load3(L.f), e01 = load3(L.f + 3), e02 = load3(L.f + 6);
+                    lpos = v0 + sx * e01 + sy * e02;
+                    const float a0 = (1.0f - sx) * (1.0f - sy), a1 = (1.0f - sx) * sy, a2 = sx * (1.0f - sy), a3 = sx * sy;
+                    lcol = a0 * load3(L.f + 9) + a1 * load3(L.f + 12) + a2 * load3(L.f + 15) + a3 * load3(L.f + 18);
+                }
+                if (F.enableShadows) {
+                    // visibilityOfLightSampleBinary (src/light.cpp:66-90): closest hit FROM the light
+                    const vec3 ip = ro + rt * rd;
+                    to = lpos;
+                    td = normalize(ip - lpos);
+                    tt = FLT_MAX;
+                    traceIsShadow = true;
+                    cShadow++;
+                    state = ST_TRACE;
+                } else {
+                    ttri = 0; // visible
+                    tt = 0.0f;
+                    state = ST_HIT_SHD;
+                }
+                break;
+            }
+            case ST_HIT_SHD: {
+                vec3 visible = lcol;
+                if (F.enableShadows) {
+                    const vec3 ip = ro + rt * rd;
+                    const bool intersects = (ttri != kNoHit);
+                    const bool expected = fabsf(tt - length(ip - lpos)) <= 5e-4f;
+                    if (!(intersects && expected)) visible = splat(0.0f);
+                }
+                const Mat m = load_material(S, hmesh, hsphere);
+                const GpuLight& L = S.lights[lightIdx];
+                if ((int)L.type == 0) { // computeContributionPointLight (src/light.cpp:151-159)
+                    const vec3 p = ro + rt * rd;
+                    const vec3 l = normalize(lpos - p);
+                    Lo = Lo + shade(F, -rd, l, visible, hn, m);
+                    lightIdx++;
+                } else { // the sampled POSITION is handed over as the light direction (src/light.cpp:191, 228)
+                    areaAcc = areaAcc + shade(F, -rd, lpos, visible, hn, m) / (1.0f * F.numShadowSamples);
+                    lightSample++;
+                }
+                state = ST_LIGHTS;
+                break;
+            }
+            case ST_SPAWN: {
+                // recursive components (src/recursive.cpp:62-80)
+                bool spawned = false;
+                if (depth < RT_MAX_RAY_DEPTH && F.enableReflections) {
+                    const Mat m = load_material(S, hmesh, hsphere);
+                    const bool reflective = (m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f);
+                    if (reflective) {
+                        // generateReflectionRay (src/recursive.cpp:91-103)
+                        vec3 rorg = ro + rt * rd;
+                        const vec3 rdir = rd - 2.f * dot(rd, hn) * hn;
+                        rorg = rorg + 0.00001f * rdir;
+                        float* fr = frames + depth * kFrameFloats;
+                        fr[0] = Lo.x, fr[1] = Lo.y, fr[2] = Lo.z;
+                        fr[3] = m.ks.x, fr[4] = m.ks.y, fr[5] = m.ks.z;
+                        if (!F.enableGlossyReflection) { // renderRaySpecularComponent (src/recursive.cpp:135-143)
+                            fr[6] = __int_as_float(CK_SPEC);
+                            to = rorg, td = rdir, tt = FLT_MAX;
+                            traceIsShadow = false;
+                            depth++;
+                            cSecondary++;
+                            state = ST_TRACE;
+                            spawned = true;
+                        } else if (F.numGlossySamples > 0) { // renderRayGlossyComponent (src/extra.cpp:464-508)
+                            fr[6] = __int_as_float(CK_GLOSSY);
+                            fr[7] = 0.5f / m.shininess; // disk radius
+                            fr[8] = rorg.x, fr[9] = rorg.y, fr[10] = rorg.z;
+                            fr[11] = rdir.x, fr[12] = rdir.y, fr[13] = rdir.z;
+                            fr[14] = hn.x, fr[15] = hn.y, fr[16] = hn.z;
+                            fr[17] = 0.0f, fr[18] = 0.0f, fr[19] = 0.0f; // accumulatedColor
+                            lightSample = 0;                              // reused as the glossy sample index i
+                            state = ST_GLOSSY_NEXT;
+                            spawned = true;
+                        }
+                    }
+                }
+                if (!spawned) {
+                    ret = Lo;
+                    state = ST_RETURN;
+                }
+                break;
+            }
+            case ST_GLOSSY_NEXT: {
+                // next accepted sample of the frame at `depth`, or the end of its loop
+                float* fr = frames + depth * kFrameFloats;
+                const vec3 rorg = make3(fr[8], fr[9], fr[10]), rdir = make3(fr[11], fr[12], fr[13]), nrm = make3(fr[14], fr[15], fr[16]);
+                const float radius = fr[7];
+                vec3 w, u, v;
+                ortho_basis(rdir, w, u, v);
+                bool launched = false;
+                while (lightSample < F.numGlossySamples) {
+                    // sampleDisk (src/extra.cpp:443-450): two draws per sample, consumed even if rejected
+                    const float r = radius * sqrtf(sampler_next(smp));
+                    const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
+                    const float dx = r * cosf(angle), dy = r * sinf(angle);
+                    const vec3 pd = normalize(w + dx * u + dy * v);
+                    lightSample++;
+                    if (dot(pd, nrm) <= 0) continue;
+                    to = rorg + 0.0001f * pd;
+                    td = pd;
+                    tt = FLT_MAX;
+                    traceIsShadow = false;
+                    fr[6] = __int_as_float(CK_GLOSSY | (int)(lightSample << 8)); // resume index
+                    depth++;
+                    cSecondary++;
+                    state = ST_TRACE;
+                    launched = true;
+                    break;
+                }
+                if (!launched) { // hitColor += accumulatedColor / float(numSamples) (src/extra.cpp:507)
+                    const vec3 acc = make3(fr[17], fr[18], fr[19]);
+                    ret = make3(fr[0], fr[1], fr[2]) + acc / float(F.numGlossySamples);
+                    state = ST_RETURN;
+                }
+                break;
+            }
+            case ST_RETURN: {
+                // `ret` is the radiance of the ray evaluated at `depth`; hand it to its caller
+                if (depth <= P.startDepth) {
+                    // pixel level: renderRays (src/recursive.cpp:10-17)
+                    if (sampleIdx != 0xffffffffu) Lsum = Lsum + ret;
+                    sampleIdx++;
+                    if (sampleIdx < nPixelRays) {
+                        float ndcX, ndcY;
+                        if (F.numPixelSamples > 1) {
+                            uint32_t s2 = seed;
+                            for (uint32_t k = 0; k < 2 * sampleIdx; k++) (void)sampler_next(s2);
+                            float ox = sampler_next(s2);
+                            float oy = sampler_next(s2);
+                            if (F.enableJitteredSampling) {
+                                const uint32_t ns = (uint32_t)roundf(sqrtf((float)F.numPixelSamples));
+                                ox /= ns;
+                                oy /= ns; // the cell offset {i / ns, j / ns} is an integer division: always 0
+                            }
+                            ndcX = ((float)px + ox) / (float)P.W * 2.f - 1.f;
+                            ndcY = ((float)py + oy) / (float)P.H * 2.f - 1.f;
+                        } else { // pixel centre (src/render.cpp:68)
+                            ndcX = ((float)px + 0.5f) / (float)P.W * 2.f - 1.f;
+                            ndcY = ((float)py + 0.5f) / (float)P.H * 2.f - 1.f;
+                        }
+                        camera_ray(P.cam, ndcX, ndcY, to, td);
+                        tt = FLT_MAX;
+                        traceIsShadow = false;
+                        depth = P.startDepth;
+                        cPrimary++;
+                        if (sampleIdx == 0) {
+                            if (P.primId) P.primId[py * P.W + px] = kNoHit;
+                            if (P.primT) P.primT[py * P.W + px] = FLT_MAX;
+                        }
+                        state = ST_TRACE;
+                    } else {
+                        const vec3 Lp = Lsum / static_cast<float>(nPixelRays);
+                        float* out = P.rgb + 3 * ((size_t)(P.H - 1 - (int)py) * P.W + px); // Screen::setPixel (src/screen.cpp:36-42)
+                        out[0] = Lp.x, out[1] = Lp.y, out[2] = Lp.z;
+                        state = ST_NEW;
+                    }
+                    break;
+                }
+                depth--;
+                float* fr = frames + depth * kFrameFloats;
+                const int kind = __float_as_int(fr[6]);
+                const vec3 ks = make3(fr[3], fr[4], fr[5]);
+                if ((kind & 0xff) == CK_SPEC) {
+                    ret = make3(fr[0], fr[1], fr[2]) + ret * ks; // hitColor += specularColor * ks
+                    state = ST_RETURN;
+                } else {
+                    const vec3 acc = make3(fr[17], fr[18], fr[19]) + ks * ret; // accumulatedColor += ks * renderRay(...)
+                    fr[17] = acc.x, fr[18] = acc.y, fr[19] = acc.z;
+                    lightSample = (uint32_t)kind >> 8;
+                    state = ST_GLOSSY_NEXT;
+                }
+                break;
+            }
+            default: state = ST_EXIT; break;
+            }
+        }
+
+        // ---- one closest-hit query per lane that has one ----
+        const unsigned long long tracing = __ballot(state == ST_TRACE);
+        if (tracing == 0ull) {
+            if (__ballot(state == ST_NEW) != 0ull) continue;
+            break;
+        }
+        if (state == ST_TRACE) {
+            trace<CULL, COUNT>(S, F.enableAccelStructure != 0, to, td, tt, ttri, stack, tc);
+            state = traceIsShadow ? ST_HIT_SHD : ST_HIT_RAD;
+        }
+    }
+
+    // ---- ray counters: wave reduction, one atomic per counter per wave ----
+    uint32_t vals[7] = { cPrimary, cShadow, cSecondary, tc.nodePairs, tc.triTests, cPixels, tc.overflow };
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        unsigned long long v = vals[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && v) atomicAdd(P.stats + i, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch closest-hit kernel (BVHInterface::intersect for n rays)
+// ---------------------------------------------------------------------------------------------
+struct IntersectParams {
+    SceneView S;
+    rt_features F;
+    float* rays; // n x 7
+    uint32_t* hits; // n x 12
+    uint32_t n;
+};
+__global__ __launch_bounds__(kBlock) void intersect_kernel(const IntersectParams P)
+{
+    __shared__ uint32_t s_stack[kStackDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P.n) return;
+    float* r = P.rays + 7 * (size_t)i;
+    const vec3 o = load3(r), d = load3(r + 3);
+    float t = r[6];
+    uint32_t tri;
+    TraceCounters tc { 0, 0, 0 };
+    trace<false, false>(P.S, P.F.enableAccelStructure != 0, o, d, t, tri, s_stack + threadIdx.x, tc);
+    uint32_t* h = P.hits + 12 * (size_t)i;
+    if (tri == kNoHit) {
+        for (int k = 0; k < 12; k++) h[k] = 0;
+        h[8] = kNoHit;
+        return;
+    }
+    Hit hit;
+    fill_hit(P.S, P.F, tri, o, d, t, hit);
+    r[6] = t;
+    h[0] = __float_as_uint(hit.normal.x), h[1] = __float_as_uint(hit.normal.y), h[2] = __float_as_uint(hit.normal.z);
+    h[3] = __float_as_uint(hit.bary.x), h[4] = __float_as_uint(hit.bary.y), h[5] = __float_as_uint(hit.bary.z);
+    h[6] = __float_as_uint(hit.uv.x), h[7] = __float_as_uint(hit.uv.y);
+    h[8] = hit.primId, h[9] = hit.mesh, h[10] = 1, h[11] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bloom (postprocessImageWithBloom, src/extra.cpp:330-416) as two LDS-tiled passes.
+// Memory rows are Screen rows (row m holds pixel row y = H-1-m).  Taps outside the image read the
+// zero border the reference pads with (padBorders, src/extra.cpp:236-256); sums run in the
+// reference's tap order with separate multiply and add.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBloomMaxF = 30;
+struct BloomParams {
+    const float* src; // pre-bloom image (pass 1) / unused (pass 2)
+    float* rgb;       // image updated in place by pass 2
+    float* tmp;       // row-filtered thresholded image
+    int W, H, F;
+    float threshold, intensity;
+    int stripeRows, rank, world; // rows written by pass 2
+    float taps[2 * kBloomMaxF + 1];
+};
+
+constexpr int kBloomRowTile = 256;
+// pass 1: threshold (applyThreshold, :186-196) + filter along x (applyFilter1dToPixel toRow, :307-314)
+__global__ __launch_bounds__(kBloomRowTile) void bloom_rows_kernel(const BloomParams P)
+{
+    __shared__ float s_px[3][kBloomRowTile + 2 * kBloomMaxF];
+    const int m = blockIdx.y, x0 = blockIdx.x * kBloomRowTile, F = P.F;
+    const int span = kBloomRowTile + 2 * F;
+    for (int i = threadIdx.x; i < span; i += kBloomRowTile) {
+        const int x = x0 - F + i;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        if (x >= 0 && x < P.W) {
+            const float* p = P.src + 3 * ((size_t)m * P.W + x);
+            r = p[0], g = p[1], b = p[2];
+            const float lum = 0.2126f * r + 0.7152f * g + 0.0722f * b; // perceivedLuminance (:177-184)
+            if (lum < P.threshold) r = g = b = 0.0f;
+        }
+        s_px[0][i] = r, s_px[1][i] = g, s_px[2][i] = b;
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= P.W) return;
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    for (int k = 0; k <= 2 * F; k++) {
+        const float f = P.taps[k];
+        ar = ar + s_px[0][threadIdx.x + k] * f;
+        ag = ag + s_px[1][threadIdx.x + k] * f;
+        ab = ab + s_px[2][threadIdx.x + k] * f;
+    }
+    float* o = P.tmp + 3 * ((size_t)m * P.W + x);
+    o[0] = ar, o[1] = ag, o[2] = ab;
+}
+
+constexpr int kBloomColX = 64, kBloomColY = 16; // output tile of pass 2: 64 columns x 16 memory rows, 256 threads
+// pass 2: filter along y (toRow = false, :317-321) + combine (:403-413).  Tap k of pixel row y reads pixel
+// row y - F + k, i.e. memory row m + F - k.
+__global__ __launch_bounds__(kBloomColX * 4) void bloom_cols_kernel(const BloomParams P)
+{
+    __shared__ float s_px[3][kBloomColY + 2 * kBloomMaxF][kBloomColX];
+    const int F = P.F, x0 = blockIdx.x * kBloomColX, m0 = blockIdx.y * kBloomColY;
+    const int tx = threadIdx.x & (kBloomColX - 1), tyBase = threadIdx.x / kBloomColX; // 4 row groups
+    const int rows = kBloomColY + 2 * F;
+    const int x = x0 + tx;
+    for (int i = tyBase; i < rows; i += 4) {
+        const int m = m0 - F + i;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        if (m >= 0 && m < P.H && x < P.W) {
+            const float* p = P.tmp + 3 * ((size_t)m * P.W + x);
+            r = p[0], g = p[1], b = p[2];
+        }
+        s_px[0][i][tx] = r, s_px[1][i][tx] = g, s_px[2][i][tx] = b;
+    }
+    __syncthreads();
+    if (x >= P.W) return;
+    for (int j = tyBase; j < kBloomColY; j += 4) {
+        const int m = m0 + j;
+        if (m >= P.H) break;
+        if (P.world > 1) { // only this rank's stripes (stripes are cut on pixel rows y = H-1-m)
+            const int y = P.H - 1 - m;
+            if ((y / P.stripeRows) % P.world != P.rank) continue;
+        }
+        float ar = 0.0f, ag = 0.0f, ab = 0.0f;
+        for (int k = 0; k <= 2 * F; k++) {
+            const float f = P.taps[k];
+            const int i = j + 2 * F - k; // local row of memory row m + F - k
+            ar = ar + s_px[0][i][tx] * f;
+            ag = ag + s_px[1][i][tx] * f;
+            ab = ab + s_px[2][i][tx] * f;
+        }
+        float* o = P.rgb + 3 * ((size_t)m * P.W + x);
+        o[0] = o[0] + ar * P.intensity;
+        o[1] = o[1] + ag * P.intensity;
+        o[2] = o[2] + ab * P.intensity;
+    }
+}
+
+// binomial / generateGaussianFilter (src/extra.cpp:258-292)
+uint64_t binomial(uint32_t n, uint32_t k)
+{
+    const uint32_t k_min = k > n - k ? n - k : k;
+    uint64_t coef = 1;
+    for (uint32_t i = 1; i <= k_min; i++) coef = (coef * (n - i + 1)) / i;
+    return coef;
+}
+void gaussian_taps(uint32_t F, float* taps)
+{
+    const uint32_t radius = F * 2 + 1;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < radius; i++) {
+        taps[i] = float(binomial(radius - 1, i));
+        sum += taps[i];
+    }
+    for (uint32_t i = 0; i < radius; i++) taps[i] /= sum;
+}
+
+int check_features(const rt_features* f)
+{
+    if (f->enableTextureMapping) {
+        rt::set_error("enableTextureMapping is not implemented on the GPU path");
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (f->enableTransparency) {
+        rt::set_error("enableTransparency is not implemented on the GPU path");
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (f->shadingModel < 0 || f->shadingModel > 3) {
+        rt::set_error("shadingModel %d out of range", f->shadingModel);
+        return RT_ERR_INVALID;
+    }
+    if (f->numPixelSamples == 0 || f->numPixelSamples > 4096) {
+        rt::set_error("numPixelSamples %u out of range", f->numPixelSamples);
+        return RT_ERR_INVALID;
+    }
+    return RT_OK;
+}
+
+template <typename T>
+T* carve(char*& p, size_t n)
+{
+    T* r = reinterpret_cast<T*>(p);
+    p += (n * sizeof(T) + 255) & ~size_t(255);
+    return r;
+}
+size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+} // namespace
+
+// =============================================================================================
+// C ABI, device side
+// =============================================================================================
+extern "C" {
+
+int rt_device_count(int* count)
+{
+    if (!count) {
+        rt::set_error("rt_device_count: null argument");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipGetDeviceCount(count));
+    return RT_OK;
+}
+int rt_set_device(int device)
+{
+    RT_HIP(hipSetDevice(device));
+    return RT_OK;
+}
+
+int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, const uint32_t* primIds,
+                    const float* materials8, uint32_t nMaterials, const float* lights22, uint32_t nLights,
+                    const float* spheres12, uint32_t nSpheres, rt_scene** out)
+{
+    if (!out || !nodes || nNodes == 0 || (nPrims && !prims) || (nMaterials && !materials8) || (nLights && !lights22)
+        || (nSpheres && !spheres12)) {
+        rt::set_error("rt_scene_create: null or empty argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    for (uint32_t i = 0; i < nLights; i++) {
+        const float ty = lights22[22 * (size_t)i];
+        if (!(ty == 0.0f || ty == 1.0f || ty == 2.0f)) {
+            rt::set_error("rt_scene_create: light %u has unknown type %g", i, (double)ty);
+            return RT_ERR_INVALID;
+        }
+    }
+    FlatScene flat;
+    const char* err = "";
+    int rc = flatten(static_cast<const RefNode*>(nodes), nNodes, static_cast<const RefPrimitive*>(prims), nPrims, primIds, nMaterials,
+                     flat, &err);
+    if (rc != RT_OK) {
+        rt::set_error("%s", err);
+        return rc;
+    }
+    rt_scene* s = new (std::nothrow) rt_scene();
+    if (!s) {
+        rt::set_error("rt_scene_create: out of memory");
+        return RT_ERR_NOMEM;
+    }
+    if (hipGetDevice(&s->device) != hipSuccess) {
+        delete s;
+        rt::set_error("rt_scene_create: no HIP device available");
+        return RT_ERR_HIP;
+    }
+    const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
+    const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
+        + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(nMaterials * sizeof(GpuMaterial))
+        + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + 256;
+    std::vector<char> host(total, 0);
+    char* hp = host.data();
+    NodePair* hPairs = carve<NodePair>(hp, nPairs);
+    TriPlane* hPlane = carve<TriPlane>(hp, nTris);
+    TriEdges* hEdges = carve<TriEdges>(hp, nTris);
+    TriAttr* hAttr = carve<TriAttr>(hp, nTris);
+    uint32_t* hBrute = carve<uint32_t>(hp, nTris);
+    GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
+    GpuLight* hLight = carve<GpuLight>(hp, nLights);
+    GpuSphere* hSph = carve<GpuSphere>(hp, nSpheres);
+    if (nPairs) memcpy(hPairs, flat.pairs.data(), nPairs * sizeof(NodePair));
+    if (nTris) {
+        memcpy(hPlane, flat.triPlane.data(), nTris * sizeof(TriPlane));
+        memcpy(hEdges, flat.triEdges.data(), nTris * sizeof(TriEdges));
+        memcpy(hAttr, flat.triAttr.data(), nTris * sizeof(TriAttr));
+        memcpy(hBrute, flat.bruteOrder.data(), nTris * 4);
+    }
+    for (uint32_t i = 0; i < nMaterials; i++) {
+        const float* m = materials8 + 8 * (size_t)i;
+        hMat[i] = GpuMaterial { { m[0], m[1], m[2] }, m[6], { m[3], m[4], m[5] }, m[7] };
+    }
+    for (uint32_t i = 0; i < nLights; i++) {
+        const float* l = lights22 + 22 * (size_t)i;
+        hLight[i].type = l[0];
+        memcpy(hLight[i].f, l + 1, 21 * 4);
+        hLight[i].pad[0] = hLight[i].pad[1] = 0.0f;
+    }
+    for (uint32_t i = 0; i < nSpheres; i++) {
+        const float* p = spheres12 + 12 * (size_t)i;
+        hSph[i] = GpuSphere { { p[0], p[1], p[2] }, p[3], { p[4], p[5], p[6] }, p[10], { p[7], p[8], p[9] }, p[11] };
+    }
+    hipError_t e = hipMalloc(&s->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_stats), S_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, S_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_work), 256);
+    if (e != hipSuccess) {
+        rt::set_error("rt_scene_create: device allocation/upload of %zu bytes failed: %s", total, hipGetErrorString(e));
+        rt_scene_destroy(s);
+        return RT_ERR_HIP;
+    }
+    s->blobBytes = total;
+    char* dp = static_cast<char*>(s->d_blob);
+    SceneView& V = s->view;
+    V.pairs = carve<NodePair>(dp, nPairs);
+    V.triPlane = carve<TriPlane>(dp, nTris);
+    V.triEdges = carve<TriEdges>(dp, nTris);
+    V.triAttr = carve<TriAttr>(dp, nTris);
+    V.bruteOrder = carve<uint32_t>(dp, nTris);
+    V.materials = carve<GpuMaterial>(dp, nMaterials);
+    V.lights = carve<GpuLight>(dp, nLights);
+    V.spheres = carve<GpuSphere>(dp, nSpheres);
+    memcpy(V.rootLo, flat.rootLo, 12);
+    memcpy(V.rootHi, flat.rootHi, 12);
+    V.rootRef = flat.rootRef;
+    V.nPairs = uint32_t(nPairs), V.nTris = uint32_t(nTris), V.nMaterials = nMaterials, V.nLights = nLights, V.nSpheres = nSpheres;
+    s->treeDepth = flat.maxDepth;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->numCUs = cus;
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s)
+{
+    if (!s) return;
+    (void)hipFree(s->d_blob);
+    (void)hipFree(s->d_stats);
+    (void)hipFree(s->d_work);
+    (void)hipFree(s->d_rgb);
+    (void)hipFree(s->d_scratch);
+    (void)hipFree(s->d_primId);
+    (void)hipFree(s->d_primT);
+    delete s;
+}
+
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height, int startDepth,
+              const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId, float* d_primT, void* stream)
+{
+    if (!scene || !camera || !features || !d_rgb || width <= 0 || height <= 0) {
+        rt::set_error("rt_render: null argument or empty frame");
+        return RT_ERR_INVALID;
+    }
+    if (startDepth < 0 || startDepth > RT_MAX_RAY_DEPTH) {
+        rt::set_error("rt_render: startDepth %d outside [0,%d]", startDepth, (int)RT_MAX_RAY_DEPTH);
+        return RT_ERR_INVALID;
+    }
+    if ((long long)width * height > (1ll << 30)) {
+        rt::set_error("rt_render: frame of %dx%d pixels exceeds the 2^30 pixel limit", width, height);
+        return RT_ERR_LIMIT;
+    }
+    int rc = check_features(features);
+    if (rc != RT_OK) return rc;
+    rt_region reg { 8, 0, 1 };
+    if (region && region->world > 1) reg = *region;
+    if (reg.stripeRows <= 0 || (reg.stripeRows % 8) != 0 || reg.rank < 0 || reg.rank >= reg.world) {
+        rt::set_error("rt_render: region {stripeRows=%d (must be a positive multiple of 8), rank=%d, world=%d} is invalid",
+                      reg.stripeRows, reg.rank, reg.world);
+        return RT_ERR_INVALID;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RenderParams P;
+    P.S = scene->view;
+    P.cam = *camera;
+    P.F = *features;
+    P.W = width, P.H = height, P.startDepth = startDepth;
+    P.tilesX = (width + 7) / 8;
+    const int tileRows = (height + 7) / 8;
+    P.stripeTileRows = reg.stripeRows / 8;
+    P.rank = reg.rank, P.world = reg.world;
+    // tile rows owned by this rank: stripes rank, rank+world, ...
+    const int stripes = (tileRows + P.stripeTileRows - 1) / P.stripeTileRows;
+    int mine = 0;
+    for (int s = reg.rank; s < stripes; s += reg.world) {
+        const int begin = s * P.stripeTileRows, end = (begin + P.stripeTileRows < tileRows) ? begin + P.stripeTileRows : tileRows;
+        mine += end - begin;
+    }
+    // the kernel enumerates full stripes; rows past the frame are rejected per pixel
+    const int myStripes = (stripes - reg.rank + reg.world - 1) / reg.world;
+    P.myTileRows = myStripes * P.stripeTileRows;
+    (void)mine;
+    P.nWork = (uint32_t)P.myTileRows * (uint32_t)P.tilesX * 64u;
+    P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
+    P.stats = scene->d_stats, P.work = scene->d_work;
+    RT_HIP(hipMemsetAsync(scene->d_stats, 0, S_COUNT * sizeof(unsigned long long), st));
+    RT_HIP(hipMemsetAsync(scene->d_work, 0, 256, st));
+    if (P.nWork == 0) return RT_OK;
+    const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
+    const uint32_t fullGrid = (P.nWork + kBlock - 1) / kBlock;
+    uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
+    if (grid > fullGrid) grid = fullGrid;
+    if (cull && !count) hipLaunchKernelGGL((render_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    else if (cull && count) hipLaunchKernelGGL((render_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    else if (!cull && !count) hipLaunchKernelGGL((render_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    else hipLaunchKernelGGL((render_kernel<false, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+size_t rt_bloom_scratch_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)width * (size_t)height * 3 * sizeof(float);
+}
+
+int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t filterSize, float threshold, float intensity,
+             const rt_region* region, void* stream)
+{
+    if (!d_rgb || !d_scratch || width <= 0 || height <= 0) {
+        rt::set_error("rt_bloom: null argument or empty frame");
+        return RT_ERR_INVALID;
+    }
+    if (filterSize > (uint32_t)kBloomMaxF) { // binomial() overflows beyond 2F = 62 (src/extra.cpp:358)
+        rt::set_error("rt_bloom: filter size %u exceeds the limit of %d", filterSize, kBloomMaxF);
+        return RT_ERR_LIMIT;
+    }
+    rt_region reg { 8, 0, 1 };
+    if (region && region->world > 1) reg = *region;
+    if (reg.stripeRows <= 0 || reg.rank < 0 || reg.rank >= reg.world) {
+        rt::set_error("rt_bloom: invalid region");
+        return RT_ERR_INVALID;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BloomParams P;
+    P.src = d_rgb, P.rgb = d_rgb, P.tmp = d_scratch;
+    P.W = width, P.H = height, P.F = (int)filterSize;
+    P.threshold = threshold, P.intensity = intensity;
+    P.stripeRows = reg.stripeRows, P.rank = reg.rank, P.world = reg.world;
+    gaussian_taps(filterSize, P.taps);
+    hipLaunchKernelGGL(bloom_rows_kernel, dim3((width + kBloomRowTile - 1) / kBloomRowTile, height), dim3(kBloomRowTile), 0, st, P);
+    RT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bloom_cols_kernel, dim3((width + kBloomColX - 1) / kBloomColX, (height + kBloomColY - 1) / kBloomColY),
+                       dim3(kBloomColX * 4), 0, st, P);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
+{
+    if (!scene) {
+        rt::set_error("rt_sync: null scene");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (stats) {
+        unsigned long long h[S_COUNT];
+        RT_HIP(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
+        stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
+        stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->reserved = 0;
+        if (h[S_OVERFLOW]) {
+            rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
+            return RT_ERR_LIMIT;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height, int startDepth,
+                    uint32_t flags, float* rgb, uint32_t* primId, float* primT, rt_stats* stats)
+{
+    if (!scene || !rgb || !features || width <= 0 || height <= 0) {
+        rt::set_error("rt_render_image: null argument or empty frame");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t px = (size_t)width * height;
+    if (px > scene->fbPixels) {
+        (void)hipFree(scene->d_rgb), (void)hipFree(scene->d_scratch), (void)hipFree(scene->d_primId), (void)hipFree(scene->d_primT);
+        scene->d_rgb = scene->d_scratch = nullptr, scene->d_primId = nullptr, scene->d_primT = nullptr;
+        scene->fbPixels = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_rgb), px * 12));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_scratch), px * 12));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primId), px * 4));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primT), px * 4));
+        scene->fbPixels = px;
+    }
+    int rc = rt_render(scene, camera, features, width, height, startDepth, nullptr, flags, scene->d_rgb, primId ? scene->d_primId : nullptr,
+                       primT ? scene->d_primT : nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    if (features->enableBloomEffect) { // src/render.cpp:48-50
+        rc = rt_bloom(scene->d_rgb, scene->d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,
+                      features->bloomFilterIntensity, nullptr, nullptr);
+        if (rc != RT_OK) return rc;
+    }
+    rc = rt_sync(scene, nullptr, stats);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipMemcpy(rgb, scene->d_rgb, px * 12, hipMemcpyDeviceToHost));
+    if (primId) RT_HIP(hipMemcpy(primId, scene->d_primId, px * 4, hipMemcpyDeviceToHost));
+    if (primT) RT_HIP(hipMemcpy(primT, scene->d_primT, px * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_intersect(rt_scene* scene, const rt_features* features, float* rays, uint32_t nRays, void* hits)
+{
+    if (!scene || !features || (nRays && (!rays || !hits))) {
+        rt::set_error("rt_intersect: null argument");
+        return RT_ERR_INVALID;
+    }
+    if (nRays == 0) return RT_OK;
+    RT_HIP(hipSetDevice(scene->device));
+    float* d_rays = nullptr;
+    uint32_t* d_hits = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)nRays * 28));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_hits), (size_t)nRays * 48);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)nRays * 28, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        IntersectParams P;
+        P.S = scene->view;
+        P.F = *features;
+        P.rays = d_rays, P.hits = d_hits, P.n = nRays;
+        hipLaunchKernelGGL(intersect_kernel, dim3((nRays + kBlock - 1) / kBlock), dim3(kBlock), 0, nullptr, P);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(rays, d_rays, (size_t)nRays * 28, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hits, d_hits, (size_t)nRays * 48, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (e != hipSuccess) {
+        rt::set_error("rt_intersect: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,127 @@
+// Device-side scene layout (what rt_scene_create uploads once to HBM) and the host-side BVH
+// container.  Internal to librt_amd.so.
+#pragma once
+#include "../../include/rt_amd.h"
+#include "rt_math.h"
+#include <vector>
+
+namespace rt {
+
+// ---- reference-layout records crossing the C ABI (src/bvh_interface.h:14-54) ----
+struct RefVertex {
+    float position[3], normal[3], texCoord[2];
+};
+struct RefPrimitive {
+    uint32_t meshID;
+    RefVertex v0, v1, v2;
+};
+static_assert(sizeof(RefPrimitive) == 100, "BVHInterface::Primitive is 100 bytes");
+struct RefNode {
+    float lower[3], upper[3];
+    uint32_t data[2];
+};
+static_assert(sizeof(RefNode) == 32, "BVHInterface::Node is 32 bytes");
+constexpr uint32_t kLeafBit = 1u << 31;
+
+// ---- flattened GPU layout ----
+// A child reference: leaf  = kLeafBit | count << 25 | first triangle (compact index)
+//                    inner = index of the NodePair holding that node's two children
+constexpr uint32_t kRefCountShift = 25;
+constexpr uint32_t kRefOffsetMask = (1u << kRefCountShift) - 1;
+constexpr uint32_t kMaxLeafCount = 63;
+constexpr int kStackDepth = 32; // per-lane traversal stack entries (LDS)
+
+// Two sibling 32-byte child records {box, ref, pad} = one 64-byte, 64-byte-aligned fetch per
+// inner-node step (the reference allocates siblings adjacently too, src/bvh.cpp:504-505).
+struct NodePair {
+    float lo0[3], hi0[3];
+    uint32_t ref0, pad0;
+    float lo1[3], hi1[3];
+    uint32_t ref1, pad1;
+};
+static_assert(sizeof(NodePair) == 64, "NodePair must be one 64-byte line");
+
+// Per-triangle constants of the reference's triangle test, hoisted out of the ray loop.  The
+// reference recomputes them for every (ray, triangle) pair from the same vertices with the same
+// IEEE operations, so the hoisted values are bit-identical to what it would compute.
+struct TriPlane { // 16 B, read for every candidate triangle
+    float n[3];   // normalize(cross(v1 - v0, v2 - v0))
+    float D;      // dot(v0, n)
+};
+struct TriEdges { // 80 B, read only when the plane distance is inside [0, ray.t]
+    float v0[3], c0x;
+    float c0y, c0z, v1x, v1y;
+    float v1z, c1[3];
+    float v2[3], c2x;
+    float c2y, c2z, pad[2];
+    // c0 = cross(v2 - v0, n), c1 = cross(v0 - v1, n), c2 = cross(v1 - v2, n)
+};
+static_assert(sizeof(TriEdges) == 80, "TriEdges layout");
+struct TriAttr { // 96 B, read once per ray for the final hit (updateHitInfo, src/bvh.cpp:18-44)
+    uint32_t primId, meshID;
+    float d00, d01, d11, denom; // dot(e1,e1), dot(e1,e2), dot(e2,e2), d00*d11 - d01*d01
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad[3];
+};
+static_assert(sizeof(TriAttr) == 96, "TriAttr layout");
+
+struct GpuMaterial { // 32 B
+    float kd[3], shininess;
+    float ks[3], transparency;
+};
+struct GpuLight { // 22 floats + pad = 96 B
+    float type;
+    float f[21];
+    float pad[2];
+};
+struct GpuSphere { // 48 B
+    float center[3], radius;
+    float kd[3], shininess;
+    float ks[3], transparency;
+};
+
+// Everything a kernel needs to read the scene; passed by value as a kernel argument.
+struct SceneView {
+    const NodePair* pairs;
+    const TriPlane* triPlane;
+    const TriEdges* triEdges;
+    const TriAttr* triAttr;
+    const uint32_t* bruteOrder; // compact triangle indices in primitives() array order
+    const GpuMaterial* materials;
+    const GpuLight* lights;
+    const GpuSphere* spheres;
+    float rootLo[3], rootHi[3];
+    uint32_t rootRef;
+    uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
+};
+
+// Host-side result of flattening (filled by flatten(), uploaded by rt_scene_create)
+struct FlatScene {
+    std::vector<NodePair> pairs;
+    std::vector<TriPlane> triPlane;
+    std::vector<TriEdges> triEdges;
+    std::vector<TriAttr> triAttr;
+    std::vector<uint32_t> bruteOrder;
+    float rootLo[3], rootHi[3];
+    uint32_t rootRef = 0;
+    uint32_t maxDepth = 0;
+};
+
+// Returns RT_OK or an error status with `err` describing it.
+int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,
+            uint32_t nMaterials, FlatScene& out, const char** err);
+
+} // namespace rt
+
+// Host-side BVH in the reference layout
+struct rt_bvh {
+    std::vector<rt::RefNode> nodes;
+    std::vector<rt::RefPrimitive> prims;
+    std::vector<uint32_t> primIds;
+    uint32_t numLevels = 0, numLeaves = 0;
+};
+
+namespace rt {
+void set_error(const char* fmt, ...);
+}

@@ -1,0 +1,286 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/rt_amd.h) against the CPU oracle on the
+same scenes, cameras and features.  Bar: primary-ray triangle ids and t bit-exact (tolerated: documented
+float ties, <= 0.01 % of pixels); ray counts equal; RGB per-channel RMSE <= 1e-3 (the GPU's powf/sinf/cosf
+differ from glibc's in the last ulps, everything else is the same IEEE arithmetic); bloom bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracer_amd import api, scenes
+
+pytestmark = pytest.mark.gpu
+
+RMSE_TOL = 1e-3  # per-channel, stated by the task for final RGB
+ID_MISMATCH_TOL = 1e-4  # fraction of pixels (99.99 % must match)
+
+BASE = dict(enableShading=1, enableShadows=1, enableReflections=1, enableNormalInterp=1, enableAccelStructure=1, shadingModel=1)
+
+
+def both_features(**kw):
+    d = dict(BASE)
+    d.update(kw)
+    return api.Features(**d), O.make_features(**d)
+
+
+def both_cameras(W, H, **kw):
+    g = api.camera_from_trackball(W, H, **kw)
+    o = O.make_camera(W, H, **kw)
+    # the two host-side camera set-ups must agree exactly before anything is rendered
+    assert list(g.quat) == list(o.quat) and list(g.position) == list(o.position)
+    assert g.halfWidth == o.halfWidth and g.halfHeight == o.halfHeight
+    return g, o
+
+
+_scene_cache = {}
+
+
+def scene_pair(name):
+    if name not in _scene_cache:
+        sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.preset(name)
+        g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+        o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+        _scene_cache[name] = (g, o, sc)
+    return _scene_cache[name]
+
+
+def rmse(a, b):
+    d = a.astype(np.float64) - b.astype(np.float64)
+    return np.sqrt((d * d).mean(axis=(0, 1)))
+
+
+def compare_frames(g, o, what, expect_exact_ids=True):
+    n = g["prim"].size
+    id_bad = np.count_nonzero(g["prim"] != o["prim"])
+    t_bad = np.count_nonzero(g["t"].view(np.uint32) != o["t"].view(np.uint32))
+    e = rmse(g["rgb"], o["rgb"])
+    print(f"{what}: id mismatches {id_bad}/{n}, t mismatches {t_bad}/{n}, rgb rmse {e}, max abs {np.abs(g['rgb'] - o['rgb']).max():.3g}")
+    assert id_bad <= ID_MISMATCH_TOL * n, f"{what}: {id_bad} primary hit ids differ"
+    assert t_bad <= ID_MISMATCH_TOL * n, f"{what}: {t_bad} primary t values differ"
+    if expect_exact_ids:
+        assert id_bad == 0 and t_bad == 0, f"{what}: expected bit-exact primary hits"
+    assert (e <= RMSE_TOL).all(), f"{what}: rgb rmse {e}"
+    return e
+
+
+def assert_ray_counts(gs, os_, what):
+    got = (gs.primaryRays, gs.shadowRays, gs.secondaryRays)
+    want = (os_["primary"], os_["shadow"], os_["secondary"])
+    print(f"{what}: rays gpu {got} oracle {want}")
+    assert got == want, f"{what}: ray counts differ"
+
+
+@pytest.mark.parametrize("name,W,H", [("cornell", 512, 512), ("monkey", 640, 360), ("teapot", 640, 360), ("knot", 480, 270)])
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_NO_CULL])
+def test_primary_hits_and_phong_frame(name, W, H, flags):
+    """configs[0]/[1] shape: Phong + shadows + mirror reflections, 2 bounces (start depth 4)."""
+    g, o, _ = scene_pair(name)
+    fg, fo = both_features()
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=4, flags=flags)
+    ro = o.render(co, fo, W, H, start_depth=4)
+    compare_frames(rg, ro, f"{name} {W}x{H} flags={flags}")
+    assert_ray_counts(rg["stats"], ro["stats"], name)
+    assert rg["stats"].pixels == W * H and rg["stats"].stackOverflows == 0
+    assert np.count_nonzero(rg["prim"] != api.NO_HIT) > 0.02 * W * H  # the object is in frame
+
+
+def test_work_counters_match_reference_traversal():
+    """Without culling the GPU walks exactly the reference's node pairs and triangle tests."""
+    g, o, _ = scene_pair("monkey")
+    fg, fo = both_features()
+    cg, co = both_cameras(320, 180)
+    rg = g.render_image(cg, fg, 320, 180, start_depth=2, flags=api.RT_RENDER_NO_CULL | api.RT_RENDER_COUNT_WORK)
+    ro = o.render(co, fo, 320, 180, start_depth=2, want_ids=False)
+    assert rg["stats"].nodePairSteps == ro["stats"]["node_pairs"]
+    assert rg["stats"].triangleTests == ro["stats"]["tri_tests"]
+    rc = g.render_image(cg, fg, 320, 180, start_depth=2, flags=api.RT_RENDER_COUNT_WORK)
+    assert rc["stats"].nodePairSteps <= rg["stats"].nodePairSteps and rc["stats"].triangleTests <= rg["stats"].triangleTests
+    assert np.array_equal(rc["prim"], rg["prim"])
+
+
+@pytest.mark.parametrize("depth", [0, 2, 6])
+def test_full_depth_and_no_bounce(depth):
+    g, o, _ = scene_pair("cornell")
+    fg, fo = both_features()
+    cg, co = both_cameras(256, 256)
+    rg = g.render_image(cg, fg, 256, 256, start_depth=depth)
+    ro = o.render(co, fo, 256, 256, start_depth=depth)
+    compare_frames(rg, ro, f"cornell depth {depth}")
+    assert_ray_counts(rg["stats"], ro["stats"], f"cornell depth {depth}")
+
+
+@pytest.mark.parametrize("name,W,H,n", [("cornell", 256, 256, 1), ("cornell", 256, 256, 4), ("monkey", 320, 180, 4), ("teapot", 320, 180, 4)])
+def test_glossy_reflections_same_sampler_sequence(name, W, H, n):
+    """configs[3] shape: glossy multi-sample, 4 bounces.  Equal ray counts show the per-pixel sampler is
+    consumed in the reference's order (rejections depend on the drawn numbers)."""
+    g, o, _ = scene_pair(name)
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=n)
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    compare_frames(rg, ro, f"{name} glossy x{n}")
+    gs, os_ = rg["stats"], ro["stats"]
+    got = (gs.primaryRays, gs.shadowRays, gs.secondaryRays)
+    want = (os_["primary"], os_["shadow"], os_["secondary"])
+    print("glossy rays", got, want)
+    # libm ulp differences in sin/cos can flip a rare grazing rejection; allow 0.01 % slack on counts
+    for a, b in zip(got, want):
+        assert abs(a - b) <= max(1, 1e-4 * b), (got, want)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+@pytest.mark.parametrize("shadows", [0, 1])
+def test_shading_models(model, shadows):
+    g, o, _ = scene_pair("monkey")
+    fg, fo = both_features(shadingModel=model, enableShadows=shadows, enableReflections=0)
+    cg, co = both_cameras(256, 144, dist=2.0)
+    compare_frames(g.render_image(cg, fg, 256, 144), o.render(co, fo, 256, 144), f"model {model} shadows {shadows}")
+
+
+def test_flat_normals_and_unshaded():
+    g, o, _ = scene_pair("teapot")
+    cg, co = both_cameras(256, 144, dist=2.0, rot_deg=(35.0, -60.0, 0.0))
+    for kw in (dict(enableNormalInterp=0), dict(enableShading=0), dict(enableShading=0, enableShadows=0, enableReflections=0)):
+        fg, fo = both_features(**kw)
+        compare_frames(g.render_image(cg, fg, 256, 144), o.render(co, fo, 256, 144), f"teapot {kw}")
+
+
+def test_area_lights():
+    """Segment (Cube preset) and parallelogram (Cornell preset) lights with sampled shadow rays."""
+    for name, ns in (("cube", 4), ("cornell_plight", 3)):
+        g, o, sc = scene_pair(name)
+        assert sc["lights"][0, 0] in (1.0, 2.0)
+        fg, fo = both_features(numShadowSamples=ns)
+        cg, co = both_cameras(192, 192)
+        rg, ro = g.render_image(cg, fg, 192, 192, start_depth=4), o.render(co, fo, 192, 192, start_depth=4)
+        compare_frames(rg, ro, f"{name} area light")
+        assert_ray_counts(rg["stats"], ro["stats"], name)
+
+
+def test_multisampled_pixels():
+    g, o, _ = scene_pair("cornell")
+    cg, co = both_cameras(128, 128)
+    for kw in (dict(numPixelSamples=4), dict(numPixelSamples=4, enableJitteredSampling=1)):
+        fg, fo = both_features(**kw)
+        rg, ro = g.render_image(cg, fg, 128, 128, start_depth=4), o.render(co, fo, 128, 128, start_depth=4)
+        e = rmse(rg["rgb"], ro["rgb"])
+        print(kw, e)
+        assert (e <= RMSE_TOL).all()
+        assert rg["stats"].primaryRays == ro["stats"]["primary"] == 4 * 128 * 128
+
+
+def test_brute_force_matches_bvh():
+    """enableAccelStructure off (the reference's own InterfaceTest configuration)."""
+    g, o, _ = scene_pair("cornell")
+    cg, co = both_cameras(128, 128)
+    fg, fo = both_features(enableAccelStructure=0)
+    rg, ro = g.render_image(cg, fg, 128, 128, start_depth=4), o.render(co, fo, 128, 128, start_depth=4)
+    compare_frames(rg, ro, "cornell brute force")
+    fg2, _ = both_features()
+    r2 = g.render_image(cg, fg2, 128, 128, start_depth=4)
+    assert np.array_equal(r2["t"], rg["t"])
+
+
+def test_spheres_and_degenerate_scenes():
+    g, o, _ = scene_pair("spheres")
+    fg, fo = both_features()
+    # camera looking at the unit box the empty BVH root keeps (rays outside it never reach the spheres)
+    cg, co = both_cameras(160, 160, dist=14.0, look_at=(0.5, 0.5, 0.5), rot_deg=(0.0, 180.0, 0.0))
+    rg, ro = g.render_image(cg, fg, 160, 160), o.render(co, fo, 160, 160)
+    compare_frames(rg, ro, "spheres")
+    g1, o1, _ = scene_pair("triangle")
+    cg, co = both_cameras(97, 61)  # ragged size: not a multiple of the 8x8 work tile
+    rg, ro = g1.render_image(cg, fg, 97, 61), o1.render(co, fo, 97, 61)
+    compare_frames(rg, ro, "single triangle 97x61")
+    assert rg["stats"].pixels == 97 * 61
+
+
+def test_batch_intersect_matches_oracle():
+    g, o, sc = scene_pair("monkey")
+    rng = np.random.RandomState(5)
+    n = 4096
+    org = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32)
+    d = tgt - org
+    d[::7] /= np.linalg.norm(d[::7], axis=1, keepdims=True)
+    d[3::97, 1] = 0.0  # axis-parallel components take the box test's zero-direction branch
+    rays = np.concatenate([org, d, np.full((n, 1), api.FLT_MAX, np.float32)], axis=1).astype(np.float32)
+    rays[5::11, 6] = 2.5  # finite ray.t
+    fg, fo = both_features()
+    got = g.intersect(fg, rays)
+    hits = 0
+    for i in range(n):
+        ok, t, h = o.intersect(fo, rays[i, 0:3], rays[i, 3:6], float(rays[i, 6]))
+        assert bool(got["hit"][i]) == ok, i
+        if ok:
+            hits += 1
+            assert np.float32(t).view(np.uint32) == got["t"][i].view(np.uint32), i
+            assert h["prim"] == got["prim"][i] and h["mesh"] == got["mesh"][i]
+            assert np.array_equal(h["normal"].view(np.uint32), got["normal"][i].view(np.uint32))
+            assert np.array_equal(h["bary"].view(np.uint32), got["bary"][i].view(np.uint32))
+    assert hits > n // 10
+
+
+@pytest.mark.parametrize("F", [1, 15, 30])
+def test_bloom_bit_exact(F):
+    torch = pytest.importorskip("torch")
+    rng = np.random.RandomState(F)
+    H, W = 203, 333
+    img = (rng.uniform(0, 1.4, (H, W, 3)) ** 3).astype(np.float32)
+    img[50:60, 100:140] = 3.0
+    want = O.bloom(img, F, 0.5, 0.8)
+    d = torch.from_numpy(img).cuda()
+    scratch = torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device="cuda")
+    api.bloom_device(d.data_ptr(), scratch.data_ptr(), W, H, F, 0.5, 0.8, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    bad = np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))
+    print(f"bloom F={F}: {bad} differing words, max abs {np.abs(got - want).max():.3g}")
+    assert bad == 0
+
+
+def test_render_image_with_bloom_flag():
+    g, o, _ = scene_pair("cornell")
+    fg, fo = both_features(enableBloomEffect=1, bloomFilterSize=7, bloomFilterThreshold=0.3)
+    cg, co = both_cameras(200, 160)
+    rg = g.render_image(cg, fg, 200, 160, start_depth=4)
+    ro = o.render(co, fo, 200, 160, start_depth=4)
+    want = O.bloom(ro["rgb"], 7, 0.3, 0.8)
+    e = rmse(rg["rgb"], want)
+    assert (e <= RMSE_TOL).all() and np.abs(want - ro["rgb"]).max() > 0.01
+
+
+def test_striped_regions_tile_the_frame():
+    """Interleaved row stripes rendered separately reproduce the full frame bit for bit."""
+    torch = pytest.importorskip("torch")
+    g, _, _ = scene_pair("monkey")
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2)
+    W, H = 320, 200
+    cg, _ = both_cameras(W, H)
+    full = g.render_image(cg, fg, W, H, start_depth=3)
+    world = 3
+    acc = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+    total = 0
+    for rank in range(world):
+        reg = api.Region(16, rank, world)
+        g.render_device(cg, fg, W, H, 3, acc.data_ptr(), region=reg, stream=torch.cuda.current_stream().cuda_stream)
+        st = g.sync(torch.cuda.current_stream().cuda_stream)
+        total += st.pixels
+    assert total == W * H
+    got = acc.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), full["rgb"].view(np.uint32))
+
+
+def test_error_reporting():
+    g, _, sc = scene_pair("cornell")
+    fg, _ = both_features(enableTransparency=1)
+    cg, _ = both_cameras(64, 64)
+    with pytest.raises(api.RtError) as e:
+        g.render_image(cg, fg, 64, 64)
+    assert e.value.code == api.RT_ERR_UNSUPPORTED
+    fg2, _ = both_features()
+    with pytest.raises(api.RtError) as e:
+        g.render_image(cg, fg2, 64, 64, start_depth=7)
+    assert e.value.code == api.RT_ERR_INVALID
