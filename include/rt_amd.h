@@ -73,8 +73,11 @@ typedef struct rt_stats {
 enum {
     RT_MAX_RAY_DEPTH = 6,      /* recursion continues while rayDepth < 6 (src/recursive.cpp:62) */
     RT_RENDER_COUNT_WORK = 1,  /* flag: also count node-pair steps and triangle tests (slower) */
-    RT_RENDER_NO_CULL = 2      /* flag: visit every box the ray enters, as the reference does
+    RT_RENDER_NO_CULL = 2,     /* flag: visit every box the ray enters, as the reference does
                                   (src/bvh.cpp:289-297), instead of skipping boxes beyond the closest hit */
+    RT_RENDER_SERIAL = 4       /* flag: evaluate each pixel as one depth-first recursion and sum radiance in the
+                                  reference's nested float order (src/recursive.cpp:25-83); the default pipeline
+                                  defers shadow rays and last-level rays and sums per pixel in fixed point */
 };
 
 typedef struct rt_bvh rt_bvh;     /* host-side BVH in the reference's node / primitive layout */
@@ -163,6 +166,11 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
  * rays: HOST n x 7 floats {origin3, direction3, t}; t is updated in place.
  * hits: HOST n x 12 dwords {normal3, barycentric3, texCoord2 (floats), primId, meshID, hit(0/1), 0}. */
 int rt_intersect(rt_scene* scene, const rt_features* features, float* rays, uint32_t nRays, void* hits);
+
+/* Diagnostic with no counterpart in the reference: checks on the GPU that the traversal's
+ * reciprocal-based slab distance (one IEEE reciprocal per ray + fused corrections) is bit-identical to
+ * the reference's `(bound - origin) / direction` over ~4M pseudo-random and edge-case operand pairs. */
+int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked);
 
 #ifdef __cplusplus
 }

@@ -890,11 +890,12 @@ int orc_intersect(const orc_scene* s, const orc_features* f, float* ray7, float*
 }
 
 int orc_render(const orc_scene* s, const orc_camera* cam, const orc_features* f, int W, int H, int startDepth,
-               int y0, int y1, float* rgb, uint32_t* primId, float* primT, uint64_t* stats, int nThreads)
+               int y0, int y1, int yStep, float* rgb, uint32_t* primId, float* primT, uint64_t* stats, int nThreads)
 {
     if (!s || !cam || !f || !rgb || W <= 0 || H <= 0) return -1;
     if (y0 < 0) y0 = 0;
     if (y1 > H) y1 = H;
+    if (yStep < 1) yStep = 1;
     Counters total;
 #ifdef _OPENMP
     if (nThreads <= 0) nThreads = omp_get_max_threads();
@@ -907,7 +908,7 @@ int orc_render(const orc_scene* s, const orc_camera* cam, const orc_features* f,
         Counters local;
         std::vector<Ray> rays;
 #pragma omp for schedule(guided)
-        for (int y = y0; y < y1; y++) {
+        for (int y = y0; y < y1; y += yStep) {
             for (int x = 0; x != W; x++) {
                 State st { *s, *f, { static_cast<uint32_t>(H * x + y) }, stats ? &local : nullptr };
                 generatePixelRays(st, *cam, x, y, W, H, rays);

@@ -70,11 +70,11 @@ void orc_bvh_copy(const orc_scene* s, uint32_t* nodes8, uint32_t* prims25, uint3
  * Returns 1 on hit. */
 int orc_intersect(const orc_scene* s, const orc_features* f, float* ray7, float* hit12);
 
-/* Whole frame (reference renderImage minus bloom), rows [y0,y1).  rgb is W*H*3 in Screen order
+/* Whole frame (reference renderImage minus bloom), rows y0, y0+yStep, ... < y1.  rgb is W*H*3 in Screen order
  * (row-flipped, src/screen.cpp:36-42).  primId/primT (optional, W*H, pixel order y*W+x) receive the
  * primary ray's gather index and t.  stats (optional) += ORC_STAT_* counters. */
 int orc_render(const orc_scene* s, const orc_camera* cam, const orc_features* f, int W, int H, int startDepth,
-               int y0, int y1, float* rgb, uint32_t* primId, float* primT, uint64_t* stats, int nThreads);
+               int y0, int y1, int yStep, float* rgb, uint32_t* primId, float* primT, uint64_t* stats, int nThreads);
 
 /* postprocessImageWithBloom (src/extra.cpp:330-416) on a Screen-order W*H*3 image, in place. */
 int orc_bloom(float* rgb, int W, int H, uint32_t filterSize, float threshold, float intensity);

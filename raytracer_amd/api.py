@@ -15,7 +15,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT = range(6)
-RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL = 1, 2
+RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL = 1, 2, 4
 NO_HIT = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -114,6 +114,7 @@ def lib():
     L.rt_render_image.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.c_uint32, f32p, u32p,
                                   f32p, C.POINTER(Stats)]
     L.rt_intersect.argtypes = [vp, C.POINTER(Features), f32p, C.c_uint32, vp]
+    L.rt_selftest_division.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _lib = L
     return L
 

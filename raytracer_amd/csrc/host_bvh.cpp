@@ -197,6 +197,13 @@ struct Flattener {
         seen[i] = 1;
         if (depth > out.maxDepth) out.maxDepth = depth;
         const RefNode& n = nodes[i];
+        for (int k = 0; k < 3; k++) {
+            const float c[2] = { n.lower[k], n.upper[k] };
+            for (float x : c) {
+                const float ax = fabsf(x);
+                if (!(x == 0.0f || (ax >= 8.6736174e-19f && ax <= 1073741824.0f))) out.fastBounds = false; // outside {0} U [2^-60, 2^30]
+            }
+        }
         if (n.data[0] & kLeafBit) {
             const uint32_t off = n.data[0] & ~kLeafBit, cnt = n.data[1];
             if (cnt > kMaxLeafCount) {

@@ -35,6 +35,19 @@ struct rt_scene {
     bool hasTextures = false;
     uint32_t treeDepth = 0;
     int numCUs = 256;
+    // wavefront pipeline buffers (sized on demand by rt_render)
+    long long* d_accum = nullptr;
+    uint32_t* d_nonfinite = nullptr;
+    size_t accumPixels = 0;
+    void* d_shadeQ = nullptr;
+    void* d_leafQ = nullptr;
+    uint32_t shadeCap = 0, leafCap = 0;
+    float* d_states = nullptr;      // path-state pool, one slot per pixel of the region
+    uint32_t* d_active[2] = { nullptr, nullptr };
+    uint32_t* d_roundCounts = nullptr; // active-list size per round
+    uint32_t stateCap = 0;
+    bool lastWasWavefront = false;
+    std::vector<int> lightTypes;
 };
 
 #define RT_HIP(call)                                                                               \
@@ -51,8 +64,10 @@ namespace {
 constexpr int kBlock = 256;     // 4 waves per workgroup
 constexpr int kFrameFloats = 20; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
+constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
+constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
 
-enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_COUNT = 8 };
+enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
 
 struct RenderParams {
     SceneView S;
@@ -117,12 +132,89 @@ struct TraceCounters {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Slab distances without a division per slab.
+//
+// A ray tests thousands of boxes with the same three divisors.  With r = RN(1/d) computed once
+// (IEEE division), RN(a/d) is recovered from q0 = a*r by two residual corrections, each a pair of
+// fused multiply-adds: e = fma(-q, d, a) is the exact remainder once q is within an ulp, and
+// fma(e, r, q) then rounds the exact quotient correctly (Markstein's theorem for a correctly
+// rounded reciprocal).  The result is bit-identical to `a / d` while no step over- or underflows;
+// rays or scenes outside that range (see ray_is_fast) take the plain-division test instead.
+// rt_selftest_division checks the identity on the GPU over random and edge-case operands.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float div_by(const float a, const float d, const float r)
+{
+    const float q0 = a * r;
+    const float e0 = fmaf(-q0, d, a);
+    const float q1 = fmaf(e0, r, q0);
+    const float e1 = fmaf(-q1, d, a);
+    return fmaf(e1, r, q1);
+}
+// |x| in {0} U [2^-60, 2^30]: differences of two such numbers are 0 or at least 2^-84 in magnitude
+__device__ __forceinline__ bool coord_in_fast_range(const float x)
+{
+    const float ax = fabsf(x);
+    return x == 0.0f || (ax >= 8.6736174e-19f && ax <= 1073741824.0f);
+}
+__device__ __forceinline__ bool dir_in_fast_range(const float x)
+{
+    const float ax = fabsf(x);
+    return x == 0.0f || (ax >= 9.31322575e-10f && ax <= 1073741824.0f); // [2^-30, 2^30]
+}
+struct RaySlabs {
+    vec3 o, d, r;
+    bool zx, zy, zz; // direction component == 0: the reference substitutes FLT_MAX / FLT_MIN
+    bool fast;
+};
+__device__ __forceinline__ RaySlabs make_slabs(const SceneView& S, const vec3 o, const vec3 d)
+{
+    RaySlabs R;
+    R.o = o, R.d = d;
+    R.r = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    R.zx = d.x == 0.0f, R.zy = d.y == 0.0f, R.zz = d.z == 0.0f;
+    R.fast = S.fastBounds != 0 && coord_in_fast_range(o.x) && coord_in_fast_range(o.y) && coord_in_fast_range(o.z)
+        && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z);
+    return R;
+}
+// same decision sequence as box_test on precomputed slab distances
+__device__ __forceinline__ bool box_decide(const float tUx, const float tUy, const float tUz, const float tLx, const float tLy,
+                                           const float tLz, const float tmax, float& tOut, bool& outside)
+{
+    float tin = sse_max(sse_min(tUz, tLz), sse_max(sse_min(tUy, tLy), sse_min(tUx, tLx)));
+    float tout = sse_min(sse_max(tUz, tLz), sse_min(sse_max(tUy, tLy), sse_max(tUx, tLx)));
+    const bool inside = 0.0f > tin;
+    const bool behind = inside && !(tout > 0.0f);
+    tin = inside ? tout : tin;
+    tout = inside ? FLT_MAX : tout;
+    outside = !inside;
+    tOut = tin;
+    return !behind && !(tin > tout) && !(0.0f > tin) && !(tin > tmax);
+}
+__device__ __forceinline__ bool box_test_fast(const float lox, const float loy, const float loz, const float hix, const float hiy,
+                                              const float hiz, const RaySlabs& R, const float tmax, float& tOut, bool& outside)
+{
+    const float qUx = div_by(hix - R.o.x, R.d.x, R.r.x), qUy = div_by(hiy - R.o.y, R.d.y, R.r.y), qUz = div_by(hiz - R.o.z, R.d.z, R.r.z);
+    const float qLx = div_by(lox - R.o.x, R.d.x, R.r.x), qLy = div_by(loy - R.o.y, R.d.y, R.r.y), qLz = div_by(loz - R.o.z, R.d.z, R.r.z);
+    return box_decide(R.zx ? FLT_MAX : qUx, R.zy ? FLT_MAX : qUy, R.zz ? FLT_MAX : qUz, R.zx ? kFltMin : qLx, R.zy ? kFltMin : qLy,
+                      R.zz ? kFltMin : qLz, tmax, tOut, outside);
+}
+__device__ __forceinline__ bool box_test_any(const float lox, const float loy, const float loz, const float hix, const float hiy,
+                                             const float hiz, const RaySlabs& R, const float tmax, float& tOut, bool& outside)
+{
+    if (R.fast) return box_test_fast(lox, loy, loz, hix, hiy, hiz, R, tmax, tOut, outside);
+    float t = 0.0f;
+    const bool h = box_test(lox, loy, loz, hix, hiy, hiz, R.o, R.d, tmax, t, outside);
+    tOut = t;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ray / triangle with hoisted per-triangle constants (archive symbols trianglePlane,
 // intersectRayWithTriangle, pointInTriangle; declared src/intersect.h:5-12).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tri_test(const SceneView& S, const uint32_t i, const vec3 o, const vec3 d, float& t, uint32_t& tri)
+__device__ __forceinline__ void tri_test_plane(const SceneView& S, const uint32_t i, const float4 pl, const vec3 o, const vec3 d, float& t,
+                                               uint32_t& tri)
 {
-    const float4 pl = reinterpret_cast<const float4*>(S.triPlane)[i];
     const vec3 n = make3(pl.x, pl.y, pl.z);
     const float tt = (pl.w - dot(o, n)) / dot(d, n);
     if (!(tt >= 0.0f)) return;
@@ -131,13 +223,17 @@ __device__ __forceinline__ void tri_test(const SceneView& S, const uint32_t i, c
     const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
     const vec3 p = d * tt + o;
     const vec3 v0 = make3(e0.x, e0.y, e0.z), c0 = make3(e0.w, e1.x, e1.y);
-    if (!(dot(c0, p - v0) >= 0.0f)) return;
     const vec3 v1 = make3(e1.z, e1.w, e2.x), c1 = make3(e2.y, e2.z, e2.w);
-    if (!(dot(c1, p - v1) >= 0.0f)) return;
     const vec3 v2 = make3(e3.x, e3.y, e3.z), c2 = make3(e3.w, e4.x, e4.y);
-    if (!(dot(c2, p - v2) >= 0.0f)) return;
-    t = tt;
-    tri = i;
+    const bool in0 = dot(c0, p - v0) >= 0.0f, in1 = dot(c1, p - v1) >= 0.0f, in2 = dot(c2, p - v2) >= 0.0f;
+    if (in0 && in1 && in2) {
+        t = tt;
+        tri = i;
+    }
+}
+__device__ __forceinline__ void tri_test(const SceneView& S, const uint32_t i, const vec3 o, const vec3 d, float& t, uint32_t& tri)
+{
+    tri_test_plane(S, i, reinterpret_cast<const float4*>(S.triPlane)[i], o, d, t, tri);
 }
 
 // Ray / sphere (archive symbol intersectRayWithShape(Sphere const&, Ray&, HitInfo&), src/intersect.h:14)
@@ -167,12 +263,15 @@ __device__ __forceinline__ bool sphere_test(const GpuSphere& sp, const vec3 o, c
 
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
+constexpr uint32_t kTraversalDone = 0xffffffffu;
 
 // ---------------------------------------------------------------------------------------------
 // Closest hit (reference intersectRayWithBVH, src/bvh.cpp:235-370).  Near child first, ties to the
 // right child, leaves tested in storage order, `t >= candidate` accepted.  With CULL a child box
 // whose entry lies beyond the closest hit so far is skipped (the reference visits it and finds
 // nothing closer); without CULL the visit order is the reference's exactly.
+// Lanes descend through inner nodes together and test leaves together (two nested loops), which
+// keeps a wave's lanes on the same code far more often than one loop alternating between both.
 // `stack` points at this lane's column of the LDS stack (stride kBlock).
 // ---------------------------------------------------------------------------------------------
 template <bool CULL, bool COUNT>
@@ -181,23 +280,25 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
 {
     tri = kNoHit;
     if (useBvh) {
+        const RaySlabs R = make_slabs(S, o, d);
         float tr;
         bool outside;
         // root box against the ray's own t; a miss returns before the sphere loop (src/bvh.cpp:264-268)
-        if (!box_test(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], o, d, t, tr, outside)) return;
+        if (!box_test_any(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], R, t, tr, outside)) return;
         int sp = 0;
         uint32_t cur = S.rootRef;
         for (;;) {
-            if (!(cur & kLeafBit)) {
+            while (!(cur & kLeafBit)) {
                 const float4* q = reinterpret_cast<const float4*>(S.pairs + cur);
                 const float4 a = q[0], b = q[1], c = q[2], e = q[3];
                 if (COUNT) tc.nodePairs++;
-                float tl = FLT_MAX, trr = FLT_MAX;
+                float tl, trr;
                 bool outL, outR;
-                bool hl = box_test(a.x, a.y, a.z, a.w, b.x, b.y, o, d, FLT_MAX, tl, outL);
-                bool hr = box_test(c.x, c.y, c.z, c.w, e.x, e.y, o, d, FLT_MAX, trr, outR);
+                bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, R, FLT_MAX, tl, outL);
+                bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, R, FLT_MAX, trr, outR);
                 const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
-                const bool leftNear = tl < trr; // equal distances: right first (src/bvh.cpp:301-310)
+                // the reference compares the distances its box test REPORTED; a missed box leaves FLT_MAX
+                const bool leftNear = (hl ? tl : FLT_MAX) < (hr ? trr : FLT_MAX); // equal: right first (src/bvh.cpp:301-310)
                 if (CULL) {
                     hl = hl && !(outL && tl > t);
                     hr = hr && !(outR && trr > t);
@@ -208,24 +309,35 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
                     else tc.overflow++;
                     sp++;
                     cur = nearRef;
-                    continue;
                 } else if (hl) {
                     cur = ref0;
-                    continue;
                 } else if (hr) {
                     cur = ref1;
-                    continue;
+                } else if (sp == 0) {
+                    cur = kTraversalDone;
+                } else {
+                    sp--;
+                    cur = (sp < kStackDepth) ? stack[sp * kBlock] : kLeafBit; // overflowed entries are dropped (counted)
                 }
-            } else {
-                const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
-                for (uint32_t k = 0; k < cnt; k++) {
-                    if (COUNT) tc.triTests++;
-                    tri_test(S, first + k, o, d, t, tri);
-                }
+            }
+            if (cur == kTraversalDone) break;
+            const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
+            const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
+            for (uint32_t k = 0; k < cnt; k += 4) {
+                const uint32_t m = cnt - k; // planes of up to four triangles in flight together
+                const float4 p0 = planes[k];
+                const float4 p1 = (m > 1) ? planes[k + 1] : p0;
+                const float4 p2 = (m > 2) ? planes[k + 2] : p0;
+                const float4 p3 = (m > 3) ? planes[k + 3] : p0;
+                if (COUNT) tc.triTests += (m > 4 ? 4 : m);
+                tri_test_plane(S, first + k, p0, o, d, t, tri);
+                if (m > 1) tri_test_plane(S, first + k + 1, p1, o, d, t, tri);
+                if (m > 2) tri_test_plane(S, first + k + 2, p2, o, d, t, tri);
+                if (m > 3) tri_test_plane(S, first + k + 3, p3, o, d, t, tri);
             }
             if (sp == 0) break;
             sp--;
-            cur = (sp < kStackDepth) ? stack[sp * kBlock] : (kLeafBit); // overflowed entries are dropped (counted)
+            cur = (sp < kStackDepth) ? stack[sp * kBlock] : kLeafBit;
         }
     } else {
         // enableAccelStructure off (src/bvh.cpp:351-363): every stored triangle, array order
@@ -758,6 +870,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
     }
 }
 
+#include "rt_wavefront.h"
+
 // ---------------------------------------------------------------------------------------------
 // Batch closest-hit kernel (BVHInterface::intersect for n rays)
 // ---------------------------------------------------------------------------------------------
@@ -883,6 +997,63 @@ __global__ __launch_bounds__(kBloomColX * 4) void bloom_cols_kernel(const BloomP
         o[0] = o[0] + ar * P.intensity;
         o[1] = o[1] + ag * P.intensity;
         o[2] = o[2] + ab * P.intensity;
+    }
+}
+
+// Self-test of div_by against IEEE division on random and edge-case operands of the range in which
+// the traversal uses it.  counts[0] += mismatching results, counts[1] += cases checked.
+__global__ __launch_bounds__(kBlock) void division_selftest_kernel(const uint32_t seed, const uint32_t perThread, unsigned long long* counts)
+{
+    uint32_t s = seed ^ (blockIdx.x * kBlock + threadIdx.x) * 2654435761u;
+    auto next = [&]() {
+        s = s * 747796405u + 2891336453u;
+        uint32_t v = s;
+        v ^= v >> ((v >> 28u) + 4u);
+        v *= 277803737u;
+        v ^= v >> 22u;
+        return v;
+    };
+    unsigned long long bad = 0, n = 0;
+    for (uint32_t i = 0; i < perThread; i++) {
+        const uint32_t mode = next() & 7u;
+        // divisor: any mantissa, exponent in [-30, 30], either sign
+        const uint32_t db = (next() & 0x807fffffu) | ((97u + next() % 61u) << 23);
+        const float d = __uint_as_float(db);
+        float a;
+        if (mode < 4) { // numerator bound - origin with both in the fast coordinate range (differences can cancel heavily)
+            const float x = __uint_as_float((next() & 0x807fffffu) | ((67u + next() % 91u) << 23));
+            float y = __uint_as_float((next() & 0x807fffffu) | ((67u + next() % 91u) << 23));
+            if (mode == 1) y = __uint_as_float(__float_as_uint(x) + (next() % 5u) - 2u); // neighbours of x
+            if (mode == 2) y = 0.0f;
+            a = x - y;
+        } else if (mode < 6) { // scene-scale numerators
+            a = ((float)(int)(next() % 2000001u) - 1000000.0f) * 1e-6f * (float)(1u << (next() % 8u));
+        } else if (mode == 6) { // exact multiples of the divisor (remainder zero) and their neighbours
+            a = d * (float)(int)(1u + next() % 4096u);
+            a = __uint_as_float(__float_as_uint(a) + (next() % 3u) - 1u);
+            if (fabsf(a) < 5.169878828e-26f) a = 0.0f; // keep to {0} U [2^-84, ...): the range ray_is_fast guarantees
+        } else {
+            a = __uint_as_float((next() & 0x807fffffu) | ((43u + next() % 115u) << 23)); // |a| in [2^-84, 2^31)
+        }
+        const float want = a / d;
+        const float got = div_by(a, d, 1.0f / d);
+        n++;
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            bad++;
+            const unsigned long long slot = atomicAdd(counts + 2, 1ull);
+            if (slot < 16) {
+                counts[4 + 2 * slot] = ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(d);
+                counts[5 + 2 * slot] = ((unsigned long long)__float_as_uint(want) << 32) | __float_as_uint(got);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += __shfl_xor(bad, off);
+        n += __shfl_xor(n, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + 0, bad);
+        atomicAdd(counts + 1, n);
     }
 }
 
@@ -1052,7 +1223,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     memcpy(V.rootHi, flat.rootHi, 12);
     V.rootRef = flat.rootRef;
     V.nPairs = uint32_t(nPairs), V.nTris = uint32_t(nTris), V.nMaterials = nMaterials, V.nLights = nLights, V.nSpheres = nSpheres;
+    V.fastBounds = flat.fastBounds ? 1u : 0u;
     s->treeDepth = flat.maxDepth;
+    for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->numCUs = cus;
     *out = s;
@@ -1069,6 +1242,14 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_scratch);
     (void)hipFree(s->d_primId);
     (void)hipFree(s->d_primT);
+    (void)hipFree(s->d_accum);
+    (void)hipFree(s->d_nonfinite);
+    (void)hipFree(s->d_shadeQ);
+    (void)hipFree(s->d_leafQ);
+    (void)hipFree(s->d_states);
+    (void)hipFree(s->d_active[0]);
+    (void)hipFree(s->d_active[1]);
+    (void)hipFree(s->d_roundCounts);
     delete s;
 }
 
@@ -1097,41 +1278,149 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         return RT_ERR_INVALID;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    RenderParams P;
+    const int tilesX = (width + 7) / 8;
+    const int tileRows = (height + 7) / 8;
+    const int stripeTileRows = reg.stripeRows / 8;
+    // stripes rank, rank+world, ... belong to this rank; the kernels enumerate full stripes and reject
+    // rows past the frame per pixel
+    const int stripes = (tileRows + stripeTileRows - 1) / stripeTileRows;
+    const int myStripes = (stripes > reg.rank) ? (stripes - reg.rank + reg.world - 1) / reg.world : 0;
+    const int myTileRows = myStripes * stripeTileRows;
+    const uint32_t nWork = (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
+    RT_HIP(hipMemsetAsync(scene->d_stats, 0, S_COUNT * sizeof(unsigned long long), st));
+    RT_HIP(hipMemsetAsync(scene->d_work, 0, 256, st));
+    scene->lastWasWavefront = false;
+    if (nWork == 0) return RT_OK;
+    const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
+    const uint32_t fullGrid = (nWork + kBlock - 1) / kBlock;
+    uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
+    if (grid > fullGrid) grid = fullGrid;
+
+    if (flags & RT_RENDER_SERIAL) {
+        RenderParams P;
+        P.S = scene->view;
+        P.cam = *camera;
+        P.F = *features;
+        P.W = width, P.H = height, P.startDepth = startDepth;
+        P.tilesX = tilesX, P.myTileRows = myTileRows, P.stripeTileRows = stripeTileRows;
+        P.rank = reg.rank, P.world = reg.world;
+        P.nWork = nWork;
+        P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
+        P.stats = scene->d_stats, P.work = scene->d_work;
+        if (cull && !count) hipLaunchKernelGGL((render_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+        else if (cull && count) hipLaunchKernelGGL((render_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+        else if (!cull && !count) hipLaunchKernelGGL((render_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL((render_kernel<false, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+        RT_HIP(hipGetLastError());
+        return RT_OK;
+    }
+
+    // ---- wavefront pipeline ----
+    const size_t px = (size_t)width * height;
+    if (px > scene->accumPixels) {
+        (void)hipFree(scene->d_accum), (void)hipFree(scene->d_nonfinite);
+        scene->d_accum = nullptr, scene->d_nonfinite = nullptr, scene->accumPixels = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_accum), px * 3 * sizeof(long long)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_nonfinite), px * sizeof(uint32_t)));
+        RT_HIP(hipMemset(scene->d_accum, 0, px * 3 * sizeof(long long)));
+        RT_HIP(hipMemset(scene->d_nonfinite, 0, px * sizeof(uint32_t)));
+        scene->accumPixels = px;
+    }
+    uint64_t want = (uint64_t)nWork * 8u;
+    if (want < (1u << 20)) want = 1u << 20;
+    if (want > kMaxQueueTasks) want = kMaxQueueTasks;
+    if (scene->shadeCap < want) {
+        (void)hipFree(scene->d_shadeQ);
+        scene->d_shadeQ = nullptr, scene->shadeCap = 0;
+        RT_HIP(hipMalloc(&scene->d_shadeQ, want * sizeof(ShadeTask)));
+        scene->shadeCap = (uint32_t)want;
+    }
+    if (scene->leafCap < want) {
+        (void)hipFree(scene->d_leafQ);
+        scene->d_leafQ = nullptr, scene->leafCap = 0;
+        RT_HIP(hipMalloc(&scene->d_leafQ, want * sizeof(LeafTask)));
+        scene->leafCap = (uint32_t)want;
+    }
+    if (scene->stateCap < nWork) {
+        (void)hipFree(scene->d_states), (void)hipFree(scene->d_active[0]), (void)hipFree(scene->d_active[1]);
+        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->stateCap = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_states), (size_t)nWork * kStateDwords * sizeof(float)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[0]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[1]), (size_t)nWork * sizeof(uint32_t)));
+        scene->stateCap = nWork;
+    }
+    if (!scene->d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_roundCounts), kMaxRounds * sizeof(uint32_t)));
+    // Rounds needed by a full tree: one ray per level of the sequential part, times the fan-out
+    uint64_t chain = 1;
+    {
+        uint32_t draws = 0;
+        for (uint32_t i = 0; i < scene->view.nLights; i++) draws += scene->lightTypes[i] ? 1 : 0;
+        const int lastLevel = (draws == 0 && features->enableGlossyReflection) ? RT_MAX_RAY_DEPTH - 1 : RT_MAX_RAY_DEPTH;
+        const int levels = lastLevel - startDepth + 1; // ray depths traced by the path stage
+        const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? features->numGlossySamples : 1;
+        uint64_t term = 1;
+        chain = 0;
+        for (int l = 0; l < levels && chain < kMaxRounds; l++) {
+            chain += term;
+            term *= (fan ? fan : 1);
+            if (!features->enableReflections) break;
+        }
+        if (chain < 1) chain = 1;
+        uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
+        chain *= nRays;
+    }
+    if (chain > kMaxRounds - 1) {
+        rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel; the round-based pipeline handles up to %u - "
+                      "use RT_RENDER_SERIAL",
+                      (unsigned long long)chain, kMaxRounds - 1);
+        return RT_ERR_LIMIT;
+    }
+    RT_HIP(hipMemsetAsync(scene->d_roundCounts, 0, kMaxRounds * sizeof(uint32_t), st));
+    WaveParams P;
     P.S = scene->view;
     P.cam = *camera;
     P.F = *features;
     P.W = width, P.H = height, P.startDepth = startDepth;
-    P.tilesX = (width + 7) / 8;
-    const int tileRows = (height + 7) / 8;
-    P.stripeTileRows = reg.stripeRows / 8;
+    P.tilesX = tilesX, P.myTileRows = myTileRows, P.stripeTileRows = stripeTileRows;
     P.rank = reg.rank, P.world = reg.world;
-    // tile rows owned by this rank: stripes rank, rank+world, ...
-    const int stripes = (tileRows + P.stripeTileRows - 1) / P.stripeTileRows;
-    int mine = 0;
-    for (int s = reg.rank; s < stripes; s += reg.world) {
-        const int begin = s * P.stripeTileRows, end = (begin + P.stripeTileRows < tileRows) ? begin + P.stripeTileRows : tileRows;
-        mine += end - begin;
-    }
-    // the kernel enumerates full stripes; rows past the frame are rejected per pixel
-    const int myStripes = (stripes - reg.rank + reg.world - 1) / reg.world;
-    P.myTileRows = myStripes * P.stripeTileRows;
-    (void)mine;
-    P.nWork = (uint32_t)P.myTileRows * (uint32_t)P.tilesX * 64u;
+    P.nWork = nWork;
     P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
     P.stats = scene->d_stats, P.work = scene->d_work;
-    RT_HIP(hipMemsetAsync(scene->d_stats, 0, S_COUNT * sizeof(unsigned long long), st));
-    RT_HIP(hipMemsetAsync(scene->d_work, 0, 256, st));
-    if (P.nWork == 0) return RT_OK;
-    const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
-    const uint32_t fullGrid = (P.nWork + kBlock - 1) / kBlock;
-    uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
-    if (grid > fullGrid) grid = fullGrid;
-    if (cull && !count) hipLaunchKernelGGL((render_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
-    else if (cull && count) hipLaunchKernelGGL((render_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
-    else if (!cull && !count) hipLaunchKernelGGL((render_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
-    else hipLaunchKernelGGL((render_kernel<false, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    P.accum = scene->d_accum, P.nonfinite = scene->d_nonfinite;
+    P.shadeQ = static_cast<ShadeTask*>(scene->d_shadeQ), P.leafQ = static_cast<LeafTask*>(scene->d_leafQ);
+    P.qCount = scene->d_work + 8;
+    P.shadeCap = scene->shadeCap, P.leafCap = scene->leafCap;
+    P.lightDraws = 0;
+    for (uint32_t i = 0; i < scene->view.nLights; i++) {
+        const int ty = scene->lightTypes[i];
+        if (ty == 1) P.lightDraws += features->numShadowSamples;
+        else if (ty == 2) P.lightDraws += 2 * features->numShadowSamples;
+    }
+    P.states = scene->d_states;
+    const uint32_t taskGrid = (uint32_t)scene->numCUs * 8u;
+    uint32_t resolveGrid = fullGrid < taskGrid ? fullGrid : taskGrid;
+    const uint32_t rounds = (uint32_t)chain - 1; // after the camera-ray round
+#define RT_LAUNCH_WAVE(CULL, COUNT)                                                                       \
+    do {                                                                                                  \
+        P.activeIn = nullptr, P.activeInCount = nullptr;                                                  \
+        P.activeOut = scene->d_active[0], P.activeOutCount = scene->d_roundCounts;                        \
+        hipLaunchKernelGGL((primary_kernel<CULL, COUNT>), dim3(grid), dim3(kBlock), 0, st, P);            \
+        for (uint32_t r = 1; r <= rounds; r++) {                                                          \
+            P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);  \
+            P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;            \
+            hipLaunchKernelGGL((round_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);      \
+        }                                                                                                 \
+        hipLaunchKernelGGL((leaf_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);           \
+        hipLaunchKernelGGL((shade_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);          \
+    } while (0)
+    if (cull && !count) RT_LAUNCH_WAVE(true, false);
+    else if (cull && count) RT_LAUNCH_WAVE(true, true);
+    else if (!cull && !count) RT_LAUNCH_WAVE(false, false);
+    else RT_LAUNCH_WAVE(false, true);
+#undef RT_LAUNCH_WAVE
+    hipLaunchKernelGGL(resolve_kernel, dim3(resolveGrid), dim3(kBlock), 0, st, P);
     RT_HIP(hipGetLastError());
+    scene->lastWasWavefront = true;
     return RT_OK;
 }
 
@@ -1191,6 +1480,16 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
             return RT_ERR_LIMIT;
         }
     }
+    if (scene->lastWasWavefront) { // did every deferred task fit its queue?
+        uint32_t q[2];
+        RT_HIP(hipMemcpy(q, scene->d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
+        if (q[0] > scene->shadeCap || q[1] > scene->leafCap) {
+            rt::set_error("task queues overflowed (%u shade tasks for %u slots, %u leaf tasks for %u slots): the frame is "
+                          "incomplete; render with RT_RENDER_SERIAL or in smaller regions",
+                          q[0], scene->shadeCap, q[1], scene->leafCap);
+            return RT_ERR_LIMIT;
+        }
+    }
     return RT_OK;
 }
 
@@ -1222,10 +1521,39 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
         if (rc != RT_OK) return rc;
     }
     rc = rt_sync(scene, nullptr, stats);
+    if (rc == RT_ERR_LIMIT && scene->lastWasWavefront) // queues too small for this frame: evaluate it depth-first instead
+        return rt_render_image(scene, camera, features, width, height, startDepth, flags | RT_RENDER_SERIAL, rgb, primId, primT, stats);
     if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpy(rgb, scene->d_rgb, px * 12, hipMemcpyDeviceToHost));
     if (primId) RT_HIP(hipMemcpy(primId, scene->d_primId, px * 4, hipMemcpyDeviceToHost));
     if (primT) RT_HIP(hipMemcpy(primT, scene->d_primT, px * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked)
+{
+    if (!mismatches || !checked) {
+        rt::set_error("rt_selftest_division: null argument");
+        return RT_ERR_INVALID;
+    }
+    unsigned long long* d = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void**>(&d), 512));
+    hipError_t e = hipMemset(d, 0, 512);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(division_selftest_kernel, dim3(4096), dim3(kBlock), 0, nullptr, seed, 1024u, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[64] = { 0 };
+    if (e == hipSuccess) e = hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
+    if (getenv("RT_AMD_DEBUG_DIV"))
+        for (int i = 0; i < 16 && i < (int)h[2]; i++)
+            fprintf(stderr, "div mismatch a=%08x d=%08x want=%08x got=%08x\n", (unsigned)(h[4 + 2 * i] >> 32), (unsigned)h[4 + 2 * i], (unsigned)(h[5 + 2 * i] >> 32), (unsigned)h[5 + 2 * i]);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        rt::set_error("rt_selftest_division: %s", hipGetErrorString(e));
+        return RT_ERR_HIP;
+    }
+    *mismatches = h[0], *checked = h[1];
     return RT_OK;
 }
 

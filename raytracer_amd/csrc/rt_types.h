@@ -94,6 +94,7 @@ struct SceneView {
     float rootLo[3], rootHi[3];
     uint32_t rootRef;
     uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
+    uint32_t fastBounds; // every box coordinate is 0 or has magnitude in [2^-60, 2^30]: reciprocal-based slab distances are exact
 };
 
 // Host-side result of flattening (filled by flatten(), uploaded by rt_scene_create)
@@ -106,6 +107,7 @@ struct FlatScene {
     float rootLo[3], rootHi[3];
     uint32_t rootRef = 0;
     uint32_t maxDepth = 0;
+    bool fastBounds = true;
 };
 
 // Returns RT_OK or an error status with `err` describing it.

@@ -68,7 +68,7 @@ def lib():
     L.orc_bvh_copy.argtypes = [C.c_void_p, u32p, u32p, u32p]
     L.orc_intersect.argtypes = [C.c_void_p, C.POINTER(OrcFeatures), f32p, f32p]
     L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcCamera), C.POINTER(OrcFeatures), C.c_int, C.c_int, C.c_int,
-                             C.c_int, C.c_int, f32p, u32p, f32p, u64p, C.c_int]
+                             C.c_int, C.c_int, C.c_int, f32p, u32p, f32p, u64p, C.c_int]
     L.orc_bloom.argtypes = [f32p, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float]
     L.orc_sampler_draws.argtypes = [C.c_uint32, C.c_int, f32p]
     L.orc_barycentric.argtypes = [f32p] * 5
@@ -151,13 +151,13 @@ class OracleScene:
         return bool(ok), float(ray[6]), dict(normal=hit[0:3].copy(), bary=hit[3:6].copy(), uv=hit[6:8].copy(),
                                              prim=int(ids[0]), mesh=int(ids[1]))
 
-    def render(self, cam, features, W, H, start_depth=0, rows=None, want_ids=True, threads=0):
+    def render(self, cam, features, W, H, start_depth=0, rows=None, want_ids=True, threads=0, row_step=1):
         rgb = np.zeros((H, W, 3), np.float32)
         pid = np.full((H, W), 0xFFFFFFFF, np.uint32) if want_ids else None
         pt = np.full((H, W), np.finfo(np.float32).max, np.float32) if want_ids else None
         stats = np.zeros(len(STAT_NAMES), np.uint64)
         y0, y1 = rows if rows else (0, H)
-        rc = lib().orc_render(self.h, C.byref(cam), C.byref(features), W, H, start_depth, y0, y1, _ptr(rgb, f32p),
+        rc = lib().orc_render(self.h, C.byref(cam), C.byref(features), W, H, start_depth, y0, y1, row_step, _ptr(rgb, f32p),
                               _ptr(pid, u32p), _ptr(pt, f32p), _ptr(stats, u64p), threads)
         if rc != 0:
             raise RuntimeError("orc_render failed")

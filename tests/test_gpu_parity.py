@@ -72,7 +72,7 @@ def assert_ray_counts(gs, os_, what):
 
 
 @pytest.mark.parametrize("name,W,H", [("cornell", 512, 512), ("monkey", 640, 360), ("teapot", 640, 360), ("knot", 480, 270)])
-@pytest.mark.parametrize("flags", [0, api.RT_RENDER_NO_CULL])
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_NO_CULL, api.RT_RENDER_SERIAL, api.RT_RENDER_SERIAL | api.RT_RENDER_NO_CULL])
 def test_primary_hits_and_phong_frame(name, W, H, flags):
     """configs[0]/[1] shape: Phong + shadows + mirror reflections, 2 bounces (start depth 4)."""
     g, o, _ = scene_pair(name)
@@ -111,16 +111,18 @@ def test_full_depth_and_no_bounce(depth):
     assert_ray_counts(rg["stats"], ro["stats"], f"cornell depth {depth}")
 
 
-@pytest.mark.parametrize("name,W,H,n", [("cornell", 256, 256, 1), ("cornell", 256, 256, 4), ("monkey", 320, 180, 4), ("teapot", 320, 180, 4)])
-def test_glossy_reflections_same_sampler_sequence(name, W, H, n):
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_SERIAL])
+@pytest.mark.parametrize("name,W,H,n", [("cornell", 256, 256, 1), ("cornell", 256, 256, 4), ("monkey", 320, 180, 4), ("teapot", 320, 180, 4),
+                                        ("knot", 240, 136, 3)])
+def test_glossy_reflections_same_sampler_sequence(name, W, H, n, flags):
     """configs[3] shape: glossy multi-sample, 4 bounces.  Equal ray counts show the per-pixel sampler is
     consumed in the reference's order (rejections depend on the drawn numbers)."""
     g, o, _ = scene_pair(name)
     fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=n)
     cg, co = both_cameras(W, H)
-    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    rg = g.render_image(cg, fg, W, H, start_depth=2, flags=flags)
     ro = o.render(co, fo, W, H, start_depth=2)
-    compare_frames(rg, ro, f"{name} glossy x{n}")
+    compare_frames(rg, ro, f"{name} glossy x{n} flags={flags}")
     gs, os_ = rg["stats"], ro["stats"]
     got = (gs.primaryRays, gs.shadowRays, gs.secondaryRays)
     want = (os_["primary"], os_["shadow"], os_["secondary"])
@@ -147,15 +149,17 @@ def test_flat_normals_and_unshaded():
         compare_frames(g.render_image(cg, fg, 256, 144), o.render(co, fo, 256, 144), f"teapot {kw}")
 
 
-def test_area_lights():
-    """Segment (Cube preset) and parallelogram (Cornell preset) lights with sampled shadow rays."""
-    for name, ns in (("cube", 4), ("cornell_plight", 3)):
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_SERIAL])
+def test_area_lights(flags):
+    """Segment (Cube preset) and parallelogram (Cornell preset) lights with sampled shadow rays; with glossy
+    reflections on, the light samples and the glossy samples interleave in one sampler sequence."""
+    for name, ns, glossy in (("cube", 4, 0), ("cornell_plight", 3, 0), ("cornell_plight", 2, 3)):
         g, o, sc = scene_pair(name)
         assert sc["lights"][0, 0] in (1.0, 2.0)
-        fg, fo = both_features(numShadowSamples=ns)
+        fg, fo = both_features(numShadowSamples=ns, enableGlossyReflection=1 if glossy else 0, numGlossySamples=max(glossy, 1))
         cg, co = both_cameras(192, 192)
-        rg, ro = g.render_image(cg, fg, 192, 192, start_depth=4), o.render(co, fo, 192, 192, start_depth=4)
-        compare_frames(rg, ro, f"{name} area light")
+        rg, ro = g.render_image(cg, fg, 192, 192, start_depth=3, flags=flags), o.render(co, fo, 192, 192, start_depth=3)
+        compare_frames(rg, ro, f"{name} area light glossy={glossy} flags={flags}")
         assert_ray_counts(rg["stats"], ro["stats"], name)
 
 
@@ -271,6 +275,35 @@ def test_striped_regions_tile_the_frame():
     assert total == W * H
     got = acc.cpu().numpy()
     assert np.array_equal(got.view(np.uint32), full["rgb"].view(np.uint32))
+
+
+def test_wavefront_matches_serial_and_is_reproducible():
+    """The default pipeline (deferred shadow / last-level rays, fixed-point pixel sums) against the depth-first
+    kernel that sums in the reference's nested order; and two runs of it bit for bit."""
+    g, _, _ = scene_pair("knot")
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=4)
+    cg, _ = both_cameras(384, 216, dist=2.2)
+    a = g.render_image(cg, fg, 384, 216, start_depth=2)
+    b = g.render_image(cg, fg, 384, 216, start_depth=2)
+    c = g.render_image(cg, fg, 384, 216, start_depth=2, flags=api.RT_RENDER_SERIAL)
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(a["prim"], c["prim"]) and np.array_equal(a["t"].view(np.uint32), c["t"].view(np.uint32))
+    assert (a["stats"].primaryRays, a["stats"].shadowRays, a["stats"].secondaryRays) == \
+           (c["stats"].primaryRays, c["stats"].shadowRays, c["stats"].secondaryRays)
+    e = rmse(a["rgb"], c["rgb"])
+    print("wavefront vs serial rmse", e, "max abs", np.abs(a["rgb"] - c["rgb"]).max())
+    assert (e < 1e-6).all()
+
+
+def test_slab_division_is_exact():
+    """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
+    total = 0
+    for seed in (1, 2, 3, 12345):
+        bad, n = C.c_uint64(0), C.c_uint64(0)
+        api.check(api.lib().rt_selftest_division(seed, C.byref(bad), C.byref(n)))
+        assert n.value >= 4_000_000 and bad.value == 0, (seed, bad.value, n.value)
+        total += n.value
+    print("division self-test cases", total)
 
 
 def test_error_reporting():
