@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -44,9 +45,16 @@ struct rt_scene {
     uint32_t shadeCap = 0, leafCap = 0;
     float* d_states = nullptr;      // path-state pool, one slot per pixel of the region
     uint32_t* d_active[2] = { nullptr, nullptr };
-    uint32_t* d_roundCounts = nullptr; // active-list size per round
+    uint32_t* d_roundCounts = nullptr; // [0, kMaxRounds): active-list size per round; then one work counter per trace launch
     uint32_t stateCap = 0;
+    void* d_pathRays = nullptr;   // stateCap ray records
+    void* d_hits = nullptr;       // hit records of the stage being traced
+    size_t hitCap = 0;
+    void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
+    size_t shadowCap = 0;
     bool lastWasWavefront = false;
+    uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
+    uint32_t bulkLanes = 1;  // the same for the deferred leaf and shadow rays (RT_AMD_BULK_LANES overrides)
     std::vector<int> lightTypes;
 };
 
@@ -66,6 +74,8 @@ constexpr int kFrameFloats = 20; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
 constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
+constexpr uint32_t kMaxTraceLaunches = kMaxRounds + 1024; // work counters for the trace launches of one frame
+constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
 
 enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
 
@@ -236,6 +246,64 @@ __device__ __forceinline__ void tri_test(const SceneView& S, const uint32_t i, c
     tri_test_plane(S, i, reinterpret_cast<const float4*>(S.triPlane)[i], o, d, t, tri);
 }
 
+// The triangles [first, first + cnt) of one leaf in storage order.  Memory latency, not arithmetic,
+// bounds a traversal step, so the work is arranged as two round trips per four triangles: the four
+// planes together, then the edge records of every triangle whose plane distance is still in range
+// together.  Acceptance then runs in storage order with the shrinking t, as the reference's loop does.
+struct EdgeRec {
+    float4 e0, e1, e2, e3, e4;
+};
+__device__ __forceinline__ EdgeRec load_edges(const SceneView& S, const uint32_t i)
+{
+    const float4* e = reinterpret_cast<const float4*>(S.triEdges + i);
+    return EdgeRec { e[0], e[1], e[2], e[3], e[4] };
+}
+__device__ __forceinline__ bool point_in_triangle(const EdgeRec& E, const vec3 p)
+{
+    const vec3 v0 = make3(E.e0.x, E.e0.y, E.e0.z), c0 = make3(E.e0.w, E.e1.x, E.e1.y);
+    const vec3 v1 = make3(E.e1.z, E.e1.w, E.e2.x), c1 = make3(E.e2.y, E.e2.z, E.e2.w);
+    const vec3 v2 = make3(E.e3.x, E.e3.y, E.e3.z), c2 = make3(E.e3.w, E.e4.x, E.e4.y);
+    const bool in0 = dot(c0, p - v0) >= 0.0f, in1 = dot(c1, p - v1) >= 0.0f, in2 = dot(c2, p - v2) >= 0.0f;
+    return in0 && in1 && in2;
+}
+template <bool COUNT>
+__device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t first, const uint32_t cnt, const vec3 o, const vec3 d, float& t,
+                                          uint32_t& tri, TraceCounters& tc)
+{
+    const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        const uint32_t m = cnt - k;
+        const float4 p0 = planes[k];
+        const float4 p1 = (m > 1) ? planes[k + 1] : p0;
+        const float4 p2 = (m > 2) ? planes[k + 2] : p0;
+        const float4 p3 = (m > 3) ? planes[k + 3] : p0;
+        if (COUNT) tc.triTests += (m > 4 ? 4 : m);
+        const float t0 = (p0.w - dot(o, make3(p0.x, p0.y, p0.z))) / dot(d, make3(p0.x, p0.y, p0.z));
+        const float t1 = (p1.w - dot(o, make3(p1.x, p1.y, p1.z))) / dot(d, make3(p1.x, p1.y, p1.z));
+        const float t2 = (p2.w - dot(o, make3(p2.x, p2.y, p2.z))) / dot(d, make3(p2.x, p2.y, p2.z));
+        const float t3 = (p3.w - dot(o, make3(p3.x, p3.y, p3.z))) / dot(d, make3(p3.x, p3.y, p3.z));
+        // in range against the t of the batch's start: necessary for acceptance, since t only shrinks
+        const bool c0 = t0 >= 0.0f && t >= t0;
+        const bool c1 = m > 1 && t1 >= 0.0f && t >= t1;
+        const bool c2 = m > 2 && t2 >= 0.0f && t >= t2;
+        const bool c3 = m > 3 && t3 >= 0.0f && t >= t3;
+        if (!(c0 || c1 || c2 || c3)) continue;
+        const uint32_t b = first + k;
+        // triangles out of range re-read the first record: no branch between the loads, no new cache line
+        const EdgeRec E0 = load_edges(S, b);
+        const EdgeRec E1 = load_edges(S, c1 ? b + 1 : b);
+        const EdgeRec E2 = load_edges(S, c2 ? b + 2 : b);
+        const EdgeRec E3 = load_edges(S, c3 ? b + 3 : b);
+        const bool i0 = point_in_triangle(E0, d * t0 + o), i1 = point_in_triangle(E1, d * t1 + o);
+        const bool i2 = point_in_triangle(E2, d * t2 + o), i3 = point_in_triangle(E3, d * t3 + o);
+        // equal distance accepted: the later candidate wins the tie
+        if (c0 && i0) t = t0, tri = b;
+        if (c1 && i1 && t >= t1) t = t1, tri = b + 1;
+        if (c2 && i2 && t >= t2) t = t2, tri = b + 2;
+        if (c3 && i3 && t >= t3) t = t3, tri = b + 3;
+    }
+}
+
 // Ray / sphere (archive symbol intersectRayWithShape(Sphere const&, Ray&, HitInfo&), src/intersect.h:14)
 __device__ __forceinline__ bool sphere_test(const GpuSphere& sp, const vec3 o, const vec3 d, float& t)
 {
@@ -322,19 +390,7 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
             }
             if (cur == kTraversalDone) break;
             const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
-            const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
-            for (uint32_t k = 0; k < cnt; k += 4) {
-                const uint32_t m = cnt - k; // planes of up to four triangles in flight together
-                const float4 p0 = planes[k];
-                const float4 p1 = (m > 1) ? planes[k + 1] : p0;
-                const float4 p2 = (m > 2) ? planes[k + 2] : p0;
-                const float4 p3 = (m > 3) ? planes[k + 3] : p0;
-                if (COUNT) tc.triTests += (m > 4 ? 4 : m);
-                tri_test_plane(S, first + k, p0, o, d, t, tri);
-                if (m > 1) tri_test_plane(S, first + k + 1, p1, o, d, t, tri);
-                if (m > 2) tri_test_plane(S, first + k + 2, p2, o, d, t, tri);
-                if (m > 3) tri_test_plane(S, first + k + 3, p3, o, d, t, tri);
-            }
+            leaf_test<COUNT>(S, first, cnt, o, d, t, tri, tc);
             if (sp == 0) break;
             sp--;
             cur = (sp < kStackDepth) ? stack[sp * kBlock] : kLeafBit;
@@ -1225,6 +1281,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.nPairs = uint32_t(nPairs), V.nTris = uint32_t(nTris), V.nMaterials = nMaterials, V.nLights = nLights, V.nSpheres = nSpheres;
     V.fastBounds = flat.fastBounds ? 1u : 0u;
     s->treeDepth = flat.maxDepth;
+    if (const char* e = getenv("RT_AMD_BULK_LANES")) s->bulkLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_GROUP_LANES")) s->groupLanes = (uint32_t)atoi(e);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->numCUs = cus;
@@ -1250,6 +1308,9 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_active[0]);
     (void)hipFree(s->d_active[1]);
     (void)hipFree(s->d_roundCounts);
+    (void)hipFree(s->d_pathRays);
+    (void)hipFree(s->d_hits);
+    (void)hipFree(s->d_shadowRays);
     delete s;
 }
 
@@ -1343,19 +1404,58 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     if (scene->stateCap < nWork) {
         (void)hipFree(scene->d_states), (void)hipFree(scene->d_active[0]), (void)hipFree(scene->d_active[1]);
-        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->stateCap = 0;
+        (void)hipFree(scene->d_pathRays);
+        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->d_pathRays = nullptr, scene->stateCap = 0;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_states), (size_t)nWork * kStateDwords * sizeof(float)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[0]), (size_t)nWork * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[1]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(&scene->d_pathRays, (size_t)nWork * sizeof(RayRec)));
         scene->stateCap = nWork;
     }
-    if (!scene->d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_roundCounts), kMaxRounds * sizeof(uint32_t)));
+    const size_t countWords = kMaxRounds + kMaxTraceLaunches;
+    if (!scene->d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_roundCounts), countWords * sizeof(uint32_t)));
+    // shadow rays: one per point light and numShadowSamples per area light for every shade task, generated and
+    // traced in chunks of tasks that fit the shadow-ray buffer
+    uint32_t raysPerTask = 0, lightDraws = 0;
+    for (uint32_t i = 0; i < scene->view.nLights; i++) {
+        const int ty = scene->lightTypes[i];
+        raysPerTask += (ty == 0) ? 1u : features->numShadowSamples;
+        if (ty == 1) lightDraws += features->numShadowSamples;
+        else if (ty == 2) lightDraws += 2 * features->numShadowSamples;
+    }
+    const bool shadows = features->enableShadows && raysPerTask > 0;
+    uint32_t chunkTasks = scene->shadeCap, nChunks = 1;
+    if (shadows) {
+        if (raysPerTask > kMaxShadowRays) {
+            rt::set_error("rt_render: %u shadow rays per hit exceed the limit of %llu", raysPerTask, (unsigned long long)kMaxShadowRays);
+            return RT_ERR_LIMIT;
+        }
+        uint64_t raysWanted = (uint64_t)scene->shadeCap * raysPerTask;
+        if (raysWanted > kMaxShadowRays) raysWanted = kMaxShadowRays - (kMaxShadowRays % raysPerTask);
+        chunkTasks = (uint32_t)(raysWanted / raysPerTask);
+        nChunks = (scene->shadeCap + chunkTasks - 1) / chunkTasks;
+        if (scene->shadowCap < raysWanted) {
+            (void)hipFree(scene->d_shadowRays);
+            scene->d_shadowRays = nullptr, scene->shadowCap = 0;
+            RT_HIP(hipMalloc(&scene->d_shadowRays, raysWanted * sizeof(RayRec)));
+            scene->shadowCap = raysWanted;
+        }
+    }
+    {
+        size_t hitsWanted = nWork;
+        if (hitsWanted < scene->leafCap) hitsWanted = scene->leafCap;
+        if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
+        if (scene->hitCap < hitsWanted) {
+            (void)hipFree(scene->d_hits);
+            scene->d_hits = nullptr, scene->hitCap = 0;
+            RT_HIP(hipMalloc(&scene->d_hits, hitsWanted * sizeof(HitRec)));
+            scene->hitCap = hitsWanted;
+        }
+    }
     // Rounds needed by a full tree: one ray per level of the sequential part, times the fan-out
     uint64_t chain = 1;
     {
-        uint32_t draws = 0;
-        for (uint32_t i = 0; i < scene->view.nLights; i++) draws += scene->lightTypes[i] ? 1 : 0;
-        const int lastLevel = (draws == 0 && features->enableGlossyReflection) ? RT_MAX_RAY_DEPTH - 1 : RT_MAX_RAY_DEPTH;
+        const int lastLevel = (lightDraws == 0 && features->enableGlossyReflection) ? RT_MAX_RAY_DEPTH - 1 : RT_MAX_RAY_DEPTH;
         const int levels = lastLevel - startDepth + 1; // ray depths traced by the path stage
         const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? features->numGlossySamples : 1;
         uint64_t term = 1;
@@ -1369,13 +1469,13 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
         chain *= nRays;
     }
-    if (chain > kMaxRounds - 1) {
-        rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel; the round-based pipeline handles up to %u - "
+    if (chain > kMaxRounds - 1 || nChunks + 8 > kMaxTraceLaunches - kMaxRounds) {
+        rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
-                      (unsigned long long)chain, kMaxRounds - 1);
+                      (unsigned long long)chain, kMaxRounds - 1, nChunks);
         return RT_ERR_LIMIT;
     }
-    RT_HIP(hipMemsetAsync(scene->d_roundCounts, 0, kMaxRounds * sizeof(uint32_t), st));
+    RT_HIP(hipMemsetAsync(scene->d_roundCounts, 0, countWords * sizeof(uint32_t), st));
     WaveParams P;
     P.S = scene->view;
     P.cam = *camera;
@@ -1390,34 +1490,79 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     P.shadeQ = static_cast<ShadeTask*>(scene->d_shadeQ), P.leafQ = static_cast<LeafTask*>(scene->d_leafQ);
     P.qCount = scene->d_work + 8;
     P.shadeCap = scene->shadeCap, P.leafCap = scene->leafCap;
-    P.lightDraws = 0;
-    for (uint32_t i = 0; i < scene->view.nLights; i++) {
-        const int ty = scene->lightTypes[i];
-        if (ty == 1) P.lightDraws += features->numShadowSamples;
-        else if (ty == 2) P.lightDraws += 2 * features->numShadowSamples;
-    }
+    P.lightDraws = lightDraws;
     P.states = scene->d_states;
+    P.pathRays = static_cast<RayRec*>(scene->d_pathRays);
+    P.hits = static_cast<const HitRec*>(scene->d_hits);
+    P.shadowRays = static_cast<RayRec*>(scene->d_shadowRays);
+    P.chunkBase = 0, P.chunkTasks = chunkTasks, P.raysPerTask = raysPerTask;
     const uint32_t taskGrid = (uint32_t)scene->numCUs * 8u;
     uint32_t resolveGrid = fullGrid < taskGrid ? fullGrid : taskGrid;
     const uint32_t rounds = (uint32_t)chain - 1; // after the camera-ray round
-#define RT_LAUNCH_WAVE(CULL, COUNT)                                                                       \
-    do {                                                                                                  \
-        P.activeIn = nullptr, P.activeInCount = nullptr;                                                  \
-        P.activeOut = scene->d_active[0], P.activeOutCount = scene->d_roundCounts;                        \
-        hipLaunchKernelGGL((primary_kernel<CULL, COUNT>), dim3(grid), dim3(kBlock), 0, st, P);            \
-        for (uint32_t r = 1; r <= rounds; r++) {                                                          \
-            P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);  \
-            P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;            \
-            hipLaunchKernelGGL((round_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);      \
-        }                                                                                                 \
-        hipLaunchKernelGGL((leaf_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);           \
-        hipLaunchKernelGGL((shade_kernel<CULL, COUNT>), dim3(taskGrid), dim3(kBlock), 0, st, P);          \
+
+    TraceParams T;
+    T.S = scene->view;
+    T.hits = static_cast<HitRec*>(scene->d_hits);
+    T.stats = scene->d_stats;
+    T.useBvh = features->enableAccelStructure ? 1u : 0u;
+    uint32_t nextFetch = kMaxRounds;
+    const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
+    // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
+    const uint32_t traceGrid = (uint32_t)scene->numCUs * 8u;
+    const bool groupOk = features->enableAccelStructure && scene->treeDepth <= 30;
+    const int reserve = (int)scene->treeDepth + 2;
+    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul,
+                            uint32_t groupLanes) {
+        T.rays = static_cast<const char*>(rays), T.rayStride = stride;
+        T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
+        T.fetch = scene->d_roundCounts + nextFetch++;
+#define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
+    do {                                                                                                                  \
+        if (groupOk && groupLanes == 4)                                                                                   \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
+        else if (groupOk && groupLanes == 8)                                                                              \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
+        else if (groupOk && groupLanes == 16)                                                                             \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
+        else if (groupOk && groupLanes == 32)                                                                             \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
+        else if (stackClass == 0) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
+        else if (stackClass == 1) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 24>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
+        else hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T);                \
     } while (0)
-    if (cull && !count) RT_LAUNCH_WAVE(true, false);
-    else if (cull && count) RT_LAUNCH_WAVE(true, true);
-    else if (!cull && !count) RT_LAUNCH_WAVE(false, false);
-    else RT_LAUNCH_WAVE(false, true);
-#undef RT_LAUNCH_WAVE
+        if (cull && !count) RT_TRACE_CASE(true, false);
+        else if (cull && count) RT_TRACE_CASE(true, true);
+        else if (!cull && !count) RT_TRACE_CASE(false, false);
+        else RT_TRACE_CASE(false, true);
+#undef RT_TRACE_CASE
+    };
+
+    P.activeIn = nullptr, P.activeInCount = nullptr;
+    P.activeOut = scene->d_active[0], P.activeOutCount = scene->d_roundCounts;
+    if (cull && !count) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, P);
+    else if (cull && count) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    else if (!cull && !count) hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, P);
+    else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    for (uint32_t r = 1; r <= rounds; r++) {
+        launch_trace(scene->d_pathRays, sizeof(RayRec), scene->d_roundCounts + (r - 1), 0, nWork, 1, scene->groupLanes);
+        P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
+        P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;
+        hipLaunchKernelGGL(path_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
+    }
+    launch_trace(scene->d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, scene->leafCap, 1, scene->bulkLanes);
+    hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
+    for (uint32_t c = 0; c < nChunks; c++) {
+        P.chunkBase = c * chunkTasks;
+        P.chunkTasks = (scene->shadeCap - P.chunkBase < chunkTasks) ? scene->shadeCap - P.chunkBase : chunkTasks;
+        if (shadows) {
+            hipLaunchKernelGGL(shadow_gen_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
+            launch_trace(scene->d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask, scene->bulkLanes);
+            P.hits = static_cast<const HitRec*>(scene->d_hits);
+        } else {
+            P.hits = nullptr;
+        }
+        hipLaunchKernelGGL(shade_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
+    }
     hipLaunchKernelGGL(resolve_kernel, dim3(resolveGrid), dim3(kBlock), 0, st, P);
     RT_HIP(hipGetLastError());
     scene->lastWasWavefront = true;

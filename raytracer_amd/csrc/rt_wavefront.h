@@ -8,18 +8,32 @@
 //     term that is added to the pixel;
 //   * rays spawned at rayDepth 6 cannot spawn anything (recursion stops at rayDepth < 6), so with
 //     point lights they draw nothing either.
-// So the path kernel walks only the sequential part - the radiance rays whose outcome decides later
-// sampler offsets - in the reference's exact order, and emits everything else as independent tasks:
-//   primary_kernel / round_kernel  per pixel DFS over radiance rays, one ray per active pixel per round;
-//                 append ShadeTask / LeafTask records
-//   leaf_kernel   traces deferred last-level rays; a hit appends a ShadeTask
-//   shade_kernel  light loop (shadow rays + shading model) per ShadeTask; adds weight * radiance to the pixel
-//   resolve_kernel converts the pixel accumulators to float RGB in Screen order
+// So the path stage walks only the sequential part - the radiance rays whose outcome decides later
+// sampler offsets - in the reference's exact order, one ray per active pixel per round, and emits
+// everything else as independent work.  Every closest-hit query of the frame goes through ONE lean
+// kernel, trace_kernel (ray records in, {t, triangle} out); the kernels around it only generate
+// rays and consume hits:
+//   primary_kernel      camera rays (traced in place: most miss the root box) -> states, round-1 rays
+//   trace_kernel        rays -> hits                                  (runs once per stage)
+//   path_logic_kernel   hits of round r -> shade tasks, leaf rays, rays of round r+1
+//   leaf_logic_kernel   hits of the deferred last-level rays -> shade tasks
+//   shadow_gen_kernel   shade tasks -> one shadow ray per light sample
+//   shade_logic_kernel  shadow hits -> visibility, shading model, weight * radiance added to the pixel
+//   resolve_kernel      pixel accumulators -> float RGB in Screen order
 // Pixel sums are kept in 64-bit fixed point so that the result does not depend on the order in which
 // tasks finish (integer adds commute): a frame is reproducible bit for bit, and equal to the
 // reference's nested float sums to ~1e-7 relative.
 #pragma once
 
+struct RayRec { // 32 B
+    float ox, oy, oz, tmax;
+    float dx, dy, dz;
+    uint32_t tag; // free for the producer (leaf rays: pixel)
+};
+struct HitRec { // 8 B
+    float t;
+    uint32_t tri; // kNoHit, compact triangle index, or kSphereBase + sphere
+};
 struct ShadeTask { // 64 B
     uint32_t pixel;   // Screen index (H-1-y)*W + x
     uint32_t matInfo; // bit 31: sphere material, low bits: mesh / sphere index
@@ -30,11 +44,10 @@ struct ShadeTask { // 64 B
     float dz, nx, ny, nz; // shading normal
 };
 static_assert(sizeof(ShadeTask) == 64, "ShadeTask layout");
-struct LeafTask { // 48 B
-    uint32_t pixel, pad;
+struct LeafTask { // 48 B: a RayRec (tag = pixel) followed by the weight of its radiance in the pixel
+    RayRec ray;
     float W[3];
-    float ox, oy, oz, dx, dy, dz;
-    float pad2;
+    float pad;
 };
 static_assert(sizeof(LeafTask) == 48, "LeafTask layout");
 
@@ -61,10 +74,14 @@ struct WaveParams {
                              // [2] path states allocated
     uint32_t shadeCap, leafCap;
     float* states;           // PathState pool: kStateDwords floats per state
-    const uint32_t* activeIn; // state indices to process this round (round_kernel)
+    const uint32_t* activeIn; // state indices whose rays were traced this round
     uint32_t* activeOut;      // survivors
     const uint32_t* activeInCount;
     uint32_t* activeOutCount;
+    RayRec* pathRays;         // ray of activeOut[i] for the next round
+    const HitRec* hits;       // hits of the rays this kernel consumes
+    RayRec* shadowRays;       // shadow_gen output, raysPerTask per shade task of the chunk
+    uint32_t chunkBase, chunkTasks, raysPerTask;
     uint32_t lightDraws;     // sampler draws one hit's light loop consumes (0 with point lights only)
 };
 
@@ -126,6 +143,173 @@ __device__ __forceinline__ void flush_counters(unsigned long long* stats, const 
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0 && v) atomicAdd(stats + i, v);
     }
+}
+
+__device__ __forceinline__ void store_ray(RayRec* r, const vec3 o, const vec3 d, const float tmax, const uint32_t tag)
+{
+    float4* q = reinterpret_cast<float4*>(r);
+    q[0] = make_float4(o.x, o.y, o.z, tmax);
+    q[1] = make_float4(d.x, d.y, d.z, __uint_as_float(tag));
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace_kernel: the closest-hit query of the reference (intersectRayWithBVH, src/bvh.cpp:235-370)
+// for an array of rays.  Persistent waves; a lane whose ray ends takes the next ray from a shared
+// counter at once instead of idling until the wave's longest ray ends (ray lengths on one model
+// spread from 1 to several hundred steps).  One node-pair or one leaf per step and lane; the
+// traversal stack lives in LDS (STACK entries per lane), everything else in registers.
+// ---------------------------------------------------------------------------------------------
+struct TraceParams {
+    SceneView S;
+    const char* rays; // RayRec at the start of each record
+    HitRec* hits;
+    const uint32_t* countPtr; // number of items = clamp(*countPtr - countSub, 0, countMaxItems) * countMul
+    uint32_t countSub, countMaxItems, countMul;
+    uint32_t rayStride;       // bytes between ray records
+    uint32_t* fetch;          // zeroed work counter of this launch
+    unsigned long long* stats;
+    uint32_t useBvh;
+};
+
+// One closest-hit query in flight on a lane.
+struct TraceLane {
+    RaySlabs R;
+    float t;
+    uint32_t tri, cur;
+    int sp;
+};
+
+// Starts a query.  Returns true when traversal steps remain, false when the query has already ended
+// (T.t / T.tri hold its result).
+template <bool COUNT>
+__device__ __forceinline__ bool trace_begin(const SceneView& S, const bool useBvh, TraceLane& T, const vec3 o, const vec3 d, const float tmax,
+                                            TraceCounters& tc)
+{
+    T.R = make_slabs(S, o, d);
+    T.t = tmax;
+    T.tri = kNoHit;
+    T.sp = 0;
+    if (useBvh) {
+        float tr;
+        bool outside;
+        // root box against the ray's own t; a miss ends the query before the sphere loop (src/bvh.cpp:264-268)
+        if (!box_test_any(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], T.R, T.t, tr, outside)) return false;
+        T.cur = S.rootRef;
+        return true;
+    }
+    // enableAccelStructure off (src/bvh.cpp:351-363): every stored triangle, array order
+    for (uint32_t k = 0; k < S.nTris; k++) {
+        if (COUNT) tc.triTests++;
+        tri_test(S, S.bruteOrder[k], o, d, T.t, T.tri);
+    }
+    for (uint32_t s = 0; s < S.nSpheres; s++)
+        if (sphere_test(S.spheres[s], o, d, T.t)) T.tri = kSphereBase + s;
+    return false;
+}
+
+// One node pair or one leaf.  Returns true when the query has ended.
+template <bool CULL, bool COUNT, int STACK>
+__device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
+{
+    bool pop = false;
+    const uint32_t cur = T.cur;
+    if (!(cur & kLeafBit)) {
+        const float4* q = reinterpret_cast<const float4*>(S.pairs + cur);
+        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        if (COUNT) tc.nodePairs++;
+        float tl, trr;
+        bool outL, outR;
+        bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, T.R, FLT_MAX, tl, outL);
+        bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, T.R, FLT_MAX, trr, outR);
+        const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
+        const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
+        if (CULL) {
+            hl = hl && !(outL && tl > T.t);
+            hr = hr && !(outR && trr > T.t);
+        }
+        if (hl && hr) {
+            if (T.sp < STACK) stack[T.sp * kBlock] = leftNear ? ref1 : ref0;
+            else tc.overflow++;
+            T.sp++;
+            T.cur = leftNear ? ref0 : ref1;
+        } else if (hl || hr) {
+            T.cur = hl ? ref0 : ref1;
+        } else {
+            pop = true;
+        }
+    } else {
+        const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
+        leaf_test<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
+        pop = true;
+    }
+    if (pop) {
+        if (T.sp == 0) {
+            for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+                if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
+            return true;
+        }
+        T.sp--;
+        T.cur = (T.sp < STACK) ? stack[T.sp * kBlock] : kLeafBit; // overflowed entries were dropped (counted)
+    }
+    return false;
+}
+
+__device__ __forceinline__ void trace_lane_clear(TraceLane& T)
+{
+    T.R.o = T.R.d = T.R.r = splat(0.0f);
+    T.R.zx = T.R.zy = T.R.zz = T.R.fast = false;
+    T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.sp = 0;
+}
+
+constexpr int kStepsPerCheck = 6; // traversal steps between two looks at the wave's idle lanes
+
+template <bool CULL, bool COUNT, int STACK>
+__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
+{
+    __shared__ uint32_t s_stack[STACK * kBlock];
+    uint32_t* const stack = s_stack + threadIdx.x;
+    const SceneView& S = P.S;
+    const int lane = threadIdx.x & 63;
+    const uint32_t have = *P.countPtr;
+    const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
+    const uint32_t total = items * P.countMul;
+    TraceCounters tc { 0, 0, 0 };
+    bool has = false, exhausted = false;
+    uint32_t idx = 0;
+    TraceLane T;
+    trace_lane_clear(T);
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle != 0ull && !exhausted) {
+            const int leader = __ffsll((long long)idle) - 1;
+            const uint32_t n = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(P.fetch, n);
+            base = __shfl(base, leader);
+            exhausted = base + n >= total;
+            if (!has) {
+                idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < total) {
+                    const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
+                    const float4 a = q[0], b = q[1];
+                    has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
+                    if (!has) P.hits[idx] = HitRec { T.t, T.tri };
+                }
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < kStepsPerCheck; it++) {
+            if (has && trace_step<CULL, COUNT, STACK>(S, T, stack, tc)) {
+                P.hits[idx] = HitRec { T.t, T.tri };
+                has = false;
+            }
+        }
+    }
+    if (COUNT || __ballot(tc.overflow != 0) != 0ull) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,11 +487,10 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     launched = true;
                     if (deferLeaves && L.loopDepth + 1 >= RT_MAX_RAY_DEPTH) {
                         // a ray at rayDepth 6 spawns nothing and draws nothing: trace it later
-                        lt.pixel = L.pixel, lt.pad = 0;
+                        lt.ray.ox = corg.x, lt.ray.oy = corg.y, lt.ray.oz = corg.z, lt.ray.tmax = FLT_MAX;
+                        lt.ray.dx = pd.x, lt.ray.dy = pd.y, lt.ray.dz = pd.z, lt.ray.tag = L.pixel;
                         lt.W[0] = cw.x, lt.W[1] = cw.y, lt.W[2] = cw.z;
-                        lt.ox = corg.x, lt.oy = corg.y, lt.oz = corg.z;
-                        lt.dx = pd.x, lt.dy = pd.y, lt.dz = pd.z;
-                        lt.pad2 = 0.0f;
+                        lt.pad = 0.0f;
                         wantLeaf = true; // leave to append; come back to PS_GLOSSY
                         break;
                     }
@@ -422,17 +605,15 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const WaveParams P)
         if (active) {
             store_header(P.states + (size_t)slot * kStateDwords, L);
             P.activeOut[pos] = slot;
+            store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
         }
     }
     flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, cPixels, cDrop);
 }
 
-// Round r >= 1: one ray for every active state of list `activeIn`; survivors go to `activeOut`.
-template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(kBlock) void round_kernel(const WaveParams P)
+// Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
+__global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    uint32_t* const stack = s_stack + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const uint32_t total = *P.activeInCount;
     uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
@@ -448,52 +629,370 @@ __global__ __launch_bounds__(kBlock) void round_kernel(const WaveParams P)
             float* s = P.states + (size_t)slot * kStateDwords;
             load_header(s, L);
             frames = s + 16;
-            L.tt = FLT_MAX;
-            trace<CULL, COUNT>(P.S, P.F.enableAccelStructure != 0, L.to, L.td, L.tt, L.ttri, stack, tc);
+            const HitRec h = P.hits[i];
+            L.tt = h.t;
+            L.ttri = h.tri;
             L.state = PS_HIT;
         }
-        auto alloc = [&](const bool) {}; // every lane of a round already owns its state's frame storage
+        auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
         advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
         const bool active = (L.state == PS_TRACE);
         const uint32_t pos = wave_fetch(P.activeOutCount, active, lane);
         if (active) {
             store_header(P.states + (size_t)slot * kStateDwords, L);
             P.activeOut[pos] = slot;
+            store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
+        }
+    }
+    flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
+}
+
+// The rest of every active pixel's sequential part in ONE launch: a lane takes an active state, traces
+// its ray, advances the recursion to the next ray, traces that, ... until the pixel ends, then takes the
+// next state.  Pixels no longer wait for the slowest ray of a round, so the frame's critical path is the
+// longest single pixel instead of the sum of every round's slowest ray.  Tracing lanes and lanes whose ray
+// has ended share a wave: the recursion code runs when enough lanes wait for it (a quarter of the wave's
+// busy lanes), or when nothing is left to trace.
+template <bool CULL, bool COUNT, int STACK>
+__global__ __launch_bounds__(kBlock) void chain_kernel(const WaveParams P, uint32_t* const fetch)
+{
+    __shared__ uint32_t s_stack[STACK * kBlock];
+    uint32_t* const stack = s_stack + threadIdx.x;
+    const SceneView& S = P.S;
+    const int lane = threadIdx.x & 63;
+    const bool useBvh = P.F.enableAccelStructure != 0;
+    const uint32_t total = *P.activeInCount;
+    uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
+    TraceCounters tc { 0, 0, 0 };
+    enum { IDLE = 0, TRACING = 1, TRACED = 2 };
+    int phase = IDLE;
+    bool exhausted = false;
+    uint32_t slot = 0;
+    TraceLane T;
+    trace_lane_clear(T);
+    for (;;) {
+        const unsigned long long idle = __ballot(phase == IDLE);
+        if (idle != 0ull && !exhausted) {
+            const int leader = __ffsll((long long)idle) - 1;
+            const uint32_t n = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(fetch, n);
+            base = __shfl(base, leader);
+            exhausted = base + n >= total;
+            if (phase == IDLE) {
+                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < total) {
+                    slot = P.activeIn[idx];
+                    const float4* q = reinterpret_cast<const float4*>(P.pathRays + idx);
+                    const float4 a = q[0], b = q[1];
+                    phase = trace_begin<COUNT>(S, useBvh, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc) ? TRACING : TRACED;
+                }
+            }
+        }
+        const unsigned long long tracing = __ballot(phase == TRACING), traced = __ballot(phase == TRACED);
+        if ((tracing | traced) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const int nTraced = __popcll(traced), nBusy = __popcll(tracing | traced);
+        if (tracing != 0ull && 4 * nTraced < nBusy) {
+#pragma unroll 1
+            for (int it = 0; it < kStepsPerCheck; it++)
+                if (phase == TRACING && trace_step<CULL, COUNT, STACK>(S, T, stack, tc)) phase = TRACED;
+        } else {
+            PathLane L;
+            L.state = PS_DONE;
+            float* frames = nullptr;
+            float* st = nullptr;
+            if (phase == TRACED) {
+                st = P.states + (size_t)slot * kStateDwords;
+                load_header(st, L);
+                frames = st + 16;
+                L.tt = T.t;
+                L.ttri = T.tri;
+                L.state = PS_HIT;
+            }
+            auto alloc = [&](const bool) {}; // active states own their frame storage
+            advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
+            if (phase == TRACED) {
+                if (L.state == PS_TRACE) {
+                    store_header(st, L);
+                    phase = trace_begin<COUNT>(S, useBvh, T, L.to, L.td, FLT_MAX, tc) ? TRACING : TRACED;
+                } else {
+                    phase = IDLE;
+                }
+            }
         }
     }
     flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Leaf kernel: deferred rays at the recursion limit.  A hit becomes a ShadeTask.
+// Group traversal: G lanes share one ray.
+//
+// The closest hit of the reference is a pure function of the set of leaves whose ancestors' boxes the
+// ray enters, and of the order in which its depth-first walk meets them: the smallest t wins, and among
+// equal t the triangle tested LAST (intersectRayTriangle accepts t <= ray.t, src/bvh.cpp:235-370).  The
+// walk's order does not depend on what was hit before, so the G lanes may visit nodes in any order as
+// long as every candidate carries its place in the reference's order.  That place is the path from the
+// root written as a heap index: 1 for the root, 2k for the child visited first, 2k+1 for the child
+// visited second; left-aligned, two leaves compare like their positions in the depth-first walk.
+// A group keeps a stack of pending inner nodes and a queue of pending leaves in LDS.  A node step pops
+// up to G nodes (one pair of boxes per lane) and pushes the children the ray enters; a leaf step pops up
+// to G leaves (one per lane) and is taken when G leaves wait or no node is left, so that each step runs
+// one kind of work on all lanes.  A ray that needs several hundred dependent steps on one lane needs a
+// few tens here - the latency of the frame's longest pixel chain shrinks by that factor.
 // ---------------------------------------------------------------------------------------------
-template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(kBlock) void leaf_kernel(const WaveParams P)
+template <int G>
+struct GroupLayout {
+    static constexpr int kQ = (G <= 16) ? 64 : 4 * G;  // node entries per group
+    static constexpr int kStride = kQ + 8;             // skewed so that groups start on different banks
+    static constexpr int kLeafQ = 3 * G + 8;           // a node step adds at most 2G leaves to fewer than G
+    static constexpr int kNodeWords = 3 * kStride;     // ref[], key[], entry distance[]
+    static constexpr int kLeafWords = 2 * kLeafQ;      // ref[], key[]
+    static constexpr int kGroupWords = kNodeWords + kLeafWords;
+    static constexpr int kGroupsPerBlock = kBlock / G;
+    static constexpr int kWords = kGroupsPerBlock * kGroupWords;
+    static constexpr int kMaxTreeDepth = (G <= 16) ? 30 : 31; // deepest tree whose reserve (depth + 2 entries) leaves room to pop G at a time
+};
+
+struct GroupLane {
+    RaySlabs R;
+    float bestT, cullT; // this lane's best hit; the group's best (for culling)
+    uint32_t bestKey, bestTri;
+    int nq, lq;         // pending nodes / leaves of the group (same value on every lane of the group)
+};
+
+// Starts a query on every lane of a group.  Returns true when traversal steps remain.
+template <int G>
+__device__ __forceinline__ bool group_begin(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const vec3 o, const vec3 d,
+                                            const float tmax)
 {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    uint32_t* const stack = s_stack + threadIdx.x;
+    T.R = make_slabs(S, o, d);
+    T.bestT = tmax, T.cullT = tmax;
+    T.bestKey = 0, T.bestTri = kNoHit;
+    T.nq = 0, T.lq = 0;
+    float tr;
+    bool outside;
+    // root box against the ray's own t; a miss ends the query before the sphere loop (src/bvh.cpp:264-268)
+    if (!box_test_any(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], T.R, tmax, tr, outside)) return false;
+    if (S.rootRef & kLeafBit) {
+        if (j == 0) q[GroupLayout<G>::kNodeWords] = S.rootRef, q[GroupLayout<G>::kNodeWords + GroupLayout<G>::kLeafQ] = 1u;
+        T.lq = 1;
+    } else {
+        if (j == 0) q[0] = S.rootRef, q[GroupLayout<G>::kStride] = 1u, q[2 * GroupLayout<G>::kStride] = __float_as_uint(0.0f);
+        T.nq = 1;
+    }
+    return true;
+}
+
+// Node step for the groups with `active`: pop up to G inner nodes, push the children the ray enters.
+template <bool CULL, bool COUNT, int G>
+__device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const int groupShift,
+                                                const int reserve, const bool active, TraceCounters& tc)
+{
+    using Lay = GroupLayout<G>;
+    constexpr uint32_t kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+    uint32_t* const lq = q + Lay::kNodeWords;
+    int n = T.nq < G ? T.nq : G;
+    const int room = Lay::kQ - reserve - T.nq;
+    if (n > room) n = room < 1 ? 1 : room; // a nearly full stack is walked one entry per step: growth is then bounded by the tree depth
+    const int base = T.nq - n;
+    bool take = active && j < n;
+    uint32_t ref = 0, key = 0;
+    if (take) {
+        const int e = T.nq - 1 - j;
+        ref = q[e];
+        key = q[Lay::kStride + e];
+        const float tentry = __uint_as_float(q[2 * Lay::kStride + e]);
+        if (CULL && tentry > T.cullT) take = false;
+    }
+    bool pushFar = false, pushNear = false;
+    uint32_t farRef = 0, farKey = 0, nearRef = 0, nearKey = 0;
+    float farT = 0.0f, nearT = 0.0f;
+    if (take) {
+        const float4* p = reinterpret_cast<const float4*>(S.pairs + ref);
+        const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+        if (COUNT) tc.nodePairs++;
+        float tl, trr;
+        bool outL, outR;
+        const bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, T.R, FLT_MAX, tl, outL);
+        const bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, T.R, FLT_MAX, trr, outR);
+        const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
+        // the child the reference visits first (src/bvh.cpp:301-310: nearer first, equal distances: right first)
+        const bool leftFirst = hl && (!hr || tl < trr);
+        const float el = outL ? tl : 0.0f, er = outR ? trr : 0.0f; // a box holding the origin is never culled
+        const bool keepL = hl && !(CULL && el > T.cullT), keepR = hr && !(CULL && er > T.cullT);
+        const uint32_t keyFirst = 2u * key, keySecond = (hl && hr) ? 2u * key + 1u : 2u * key;
+        if (leftFirst) {
+            pushNear = keepL, nearRef = ref0, nearKey = keyFirst, nearT = el;
+            pushFar = keepR, farRef = ref1, farKey = keySecond, farT = er;
+        } else {
+            pushNear = keepR, nearRef = ref1, nearKey = keyFirst, nearT = er;
+            pushFar = keepL, farRef = ref0, farKey = keySecond, farT = el;
+        }
+    }
+    const bool farLeaf = pushFar && (farRef & kLeafBit), nearLeaf = pushNear && (nearRef & kLeafBit);
+    const bool farNode = pushFar && !farLeaf, nearNode = pushNear && !nearLeaf;
+    const uint32_t mFarN = (uint32_t)(__ballot(farNode) >> groupShift) & kGroupMask;
+    const uint32_t mNearN = (uint32_t)(__ballot(nearNode) >> groupShift) & kGroupMask;
+    const uint32_t mFarL = (uint32_t)(__ballot(farLeaf) >> groupShift) & kGroupMask;
+    const uint32_t mNearL = (uint32_t)(__ballot(nearLeaf) >> groupShift) & kGroupMask;
+    if (!active) return;
+    const uint32_t below = (1u << j) - 1u;
+    const int nFarN = __popc(mFarN), nFarL = __popc(mFarL);
+    __builtin_amdgcn_wave_barrier(); // every pop of this step precedes its pushes
+    if (farNode) {
+        const int e = base + __popc(mFarN & below);
+        q[e] = farRef, q[Lay::kStride + e] = farKey, q[2 * Lay::kStride + e] = __float_as_uint(farT);
+    }
+    if (nearNode) { // nearer children on top: they are popped first
+        const int e = base + nFarN + __popc(mNearN & below);
+        q[e] = nearRef, q[Lay::kStride + e] = nearKey, q[2 * Lay::kStride + e] = __float_as_uint(nearT);
+    }
+    if (farLeaf) {
+        const int e = T.lq + __popc(mFarL & below);
+        lq[e] = farRef, lq[Lay::kLeafQ + e] = farKey;
+    }
+    if (nearLeaf) {
+        const int e = T.lq + nFarL + __popc(mNearL & below);
+        lq[e] = nearRef, lq[Lay::kLeafQ + e] = nearKey;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T.nq = base + nFarN + __popc(mNearN);
+    T.lq = T.lq + nFarL + __popc(mNearL);
+}
+
+// Leaf step for the groups with `active`: pop up to G leaves, test their triangles, refresh the group's best.
+template <bool COUNT, int G>
+__device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const bool active,
+                                                TraceCounters& tc)
+{
+    using Lay = GroupLayout<G>;
+    uint32_t* const lq = q + Lay::kNodeWords;
+    const int n = T.lq < G ? T.lq : G;
+    if (active && j < n) {
+        const int e = T.lq - 1 - j;
+        const uint32_t ref = lq[e], key = lq[Lay::kLeafQ + e];
+        const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+        float tl = T.bestT;
+        uint32_t tril = kNoHit;
+        leaf_test<COUNT>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc);
+        if (tril != kNoHit) {
+            const uint32_t aligned = key << __clz(key);
+            // tl <= bestT here: a closer hit wins, an equal one wins if the reference meets this leaf later
+            if (tl < T.bestT || aligned > T.bestKey) T.bestT = tl, T.bestKey = aligned, T.bestTri = tril;
+        }
+    }
+    if (active) T.lq -= n;
+    float bt = T.bestT;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
+    if (active) T.cullT = bt;
+}
+
+// The group's result on every lane of the group (all lanes of the wave must call).
+template <int G>
+__device__ __forceinline__ void group_finish(const SceneView& S, GroupLane& T, const bool active)
+{
+    float bt = T.bestT;
+    uint32_t bk = T.bestKey, bi = T.bestTri;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+        const float ot = __shfl_xor(bt, off);
+        const uint32_t ok = __shfl_xor(bk, off), oi = __shfl_xor(bi, off);
+        if (ot < bt || (ot == bt && ok > bk)) bt = ot, bk = ok, bi = oi;
+    }
+    if (!active) return;
+    T.bestT = bt, T.bestKey = bk, T.bestTri = bi;
+    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+        if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.bestT)) T.bestTri = kSphereBase + s;
+}
+
+// trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
+// full stack can always be walked one entry at a time.
+template <bool CULL, bool COUNT, int G>
+__global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P, const int reserve)
+{
+    using Lay = GroupLayout<G>;
+    __shared__ uint32_t s_q[Lay::kWords];
+    const SceneView& S = P.S;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (G - 1), leaderLane = lane - j, groupShift = leaderLane;
+    uint32_t* const q = s_q + (threadIdx.x / G) * Lay::kGroupWords;
+    const uint32_t have = *P.countPtr;
+    const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
+    const uint32_t total = items * P.countMul;
+    TraceCounters tc { 0, 0, 0 };
+    bool has = false, exhausted = false; // has: same on every lane of a group
+    uint32_t idx = 0;
+    GroupLane T;
+    T.R.o = T.R.d = T.R.r = splat(0.0f);
+    T.R.zx = T.R.zy = T.R.zz = T.R.fast = false;
+    T.bestT = T.cullT = 0.0f, T.bestKey = 0, T.bestTri = kNoHit, T.nq = T.lq = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has && j == 0);
+        if (idle != 0ull && !exhausted) {
+            const int first = __ffsll((long long)idle) - 1;
+            const uint32_t n = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(P.fetch, n);
+            base = __shfl(base, first);
+            exhausted = base + n >= total;
+            if (!has) {
+                idx = base + (uint32_t)__popcll(idle & ((1ull << leaderLane) - 1ull));
+                if (idx < total) {
+                    const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
+                    const float4 a = r[0], b = r[1];
+                    has = group_begin<G>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
+                    if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
+                }
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < 4; it++) {
+            const bool wantLeaf = has && (T.lq >= G || (T.nq == 0 && T.lq > 0));
+            const bool wantNode = has && !wantLeaf && T.nq > 0;
+            if (__ballot(wantNode) != 0ull) group_node_step<CULL, COUNT, G>(S, T, q, j, groupShift, reserve, wantNode, tc);
+            if (__ballot(wantLeaf) != 0ull) group_leaf_step<COUNT, G>(S, T, q, j, wantLeaf, tc);
+            const bool done = has && T.nq == 0 && T.lq == 0;
+            if (__ballot(done) != 0ull) {
+                group_finish<G>(S, T, done);
+                if (done) {
+                    if (j == 0) P.hits[idx] = HitRec { T.bestT, T.bestTri };
+                    has = false;
+                }
+            }
+        }
+    }
+    if (COUNT) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
+}
+
+// Deferred rays at the recursion limit: a hit becomes a ShadeTask.
+__global__ __launch_bounds__(kBlock) void leaf_logic_kernel(const WaveParams P)
+{
     const int lane = threadIdx.x & 63;
     const uint32_t total = min(P.qCount[1], P.leafCap);
     TraceCounters tc { 0, 0, 0 };
     uint32_t cDrop = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) { // block-uniform trip count
         const uint32_t i = base + threadIdx.x;
-        const bool active = i < total;
         ShadeTask st;
         bool want = false;
-        if (active) {
-            const float4* q = reinterpret_cast<const float4*>(P.leafQ + i);
-            const float4 a = q[0], b = q[1], c = q[2];
-            const uint32_t pixel = __float_as_uint(a.x);
-            const vec3 W = make3(a.z, a.w, b.x), o = make3(b.y, b.z, b.w), d = make3(c.x, c.y, c.z);
-            float t = FLT_MAX;
-            uint32_t tri;
-            trace<CULL, COUNT>(P.S, P.F.enableAccelStructure != 0, o, d, t, tri, stack, tc);
-            if (tri != kNoHit) {
+        if (i < total) {
+            const HitRec hr = P.hits[i];
+            if (hr.tri != kNoHit) {
+                const float4* q = reinterpret_cast<const float4*>(P.leafQ + i);
+                const float4 a = q[0], b = q[1], c = q[2];
+                const vec3 o = make3(a.x, a.y, a.z), d = make3(b.x, b.y, b.z), W = make3(c.x, c.y, c.z);
                 Hit h;
-                fill_hit(P.S, P.F, tri, o, d, t, h);
-                const vec3 p = o + t * d;
-                st.pixel = pixel;
+                fill_hit(P.S, P.F, hr.tri, o, d, hr.t, h);
+                const vec3 p = o + hr.t * d;
+                st.pixel = __float_as_uint(b.w);
                 st.matInfo = h.mesh | (h.isSphere ? 0x80000000u : 0u);
                 st.smp = 0, st.pad = 0;
                 st.W[0] = W.x, st.W[1] = W.y, st.W[2] = W.z;
@@ -508,71 +1007,96 @@ __global__ __launch_bounds__(kBlock) void leaf_kernel(const WaveParams P)
     flush_counters(P.stats, lane, 0, 0, 0, tc, 0, cDrop);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Shade kernel: computeLightContribution (src/light.cpp:262-276) for one hit per lane.
-// ---------------------------------------------------------------------------------------------
-template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(kBlock) void shade_kernel(const WaveParams P)
+// Position and colour of light sample (li, s) for a hit whose light loop starts at sampler state smp.
+// Walks the lights in order so that area-light draws are consumed exactly as computeLightContribution does
+// (src/light.cpp:262-276).  Calls fn(rayIndex, light, lpos, lcol) for every sample.
+template <typename Fn>
+__device__ __forceinline__ void for_each_light_sample(const SceneView& S, const rt_features& F, uint32_t smp, Fn&& fn)
 {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    uint32_t* const stack = s_stack + threadIdx.x;
-    const SceneView& S = P.S;
-    const rt_features& F = P.F;
-    const int lane = threadIdx.x & 63;
-    const uint32_t total = min(P.qCount[0], P.shadeCap);
-    TraceCounters tc { 0, 0, 0 };
-    uint32_t cShadow = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-        const float4* q = reinterpret_cast<const float4*>(P.shadeQ + i);
-        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
-        const uint32_t pixel = __float_as_uint(a.x), matInfo = __float_as_uint(a.y);
-        uint32_t smp = __float_as_uint(a.z);
-        const vec3 W = make3(b.x, b.y, b.z), p = make3(b.w, c.x, c.y), rd = make3(c.z, c.w, e.x), hn = make3(e.y, e.z, e.w);
-        const Mat m = load_material(S, matInfo & 0x7fffffffu, (matInfo >> 31) != 0);
-        vec3 Lo = splat(0.0f);
-        for (uint32_t li = 0; li < S.nLights; li++) {
-            const GpuLight& L = S.lights[li];
-            const int type = (int)L.type;
-            const uint32_t nSamples = (type == 0) ? 1u : F.numShadowSamples;
-            vec3 areaAcc = splat(0.0f);
-            for (uint32_t s = 0; s < nSamples; s++) {
-                vec3 lpos, lcol;
-                if (type == 0) {
-                    lpos = load3(L.f);
-                    lcol = load3(L.f + 3);
-                } else if (type == 1) { // sampleSegmentLight (src/light.cpp:25-29)
-                    const float u = sampler_next(smp);
-                    const vec3 e0 = load3(L.f), e1 = load3(L.f + 3), c0 = load3(L.f + 6), c1 = load3(L.f + 9);
-                    lpos = e0 + u * (e1 - e0);
-                    lcol = c0 + u * (c1 - c0);
-                } else { // sampleParallelogramLight (src/light.cpp:40-53)
-                    const float sx = sampler_next(smp);
-                    const float sy = sampler_next(smp);
-                    lpos = load3(L.f) + sx * load3(L.f + 3) + sy * load3(L.f + 6);
-                    const float a0 = (1.0f - sx) * (1.0f - sy), a1 = (1.0f - sx) * sy, a2 = sx * (1.0f - sy), a3 = sx * sy;
-                    lcol = a0 * load3(L.f + 9) + a1 * load3(L.f + 12) + a2 * load3(L.f + 15) + a3 * load3(L.f + 18);
-                }
-                vec3 visible = lcol;
-                if (F.enableShadows) { // visibilityOfLightSampleBinary (src/light.cpp:66-90)
-                    const vec3 sd = normalize(p - lpos);
-                    float t = FLT_MAX;
-                    uint32_t tri;
-                    cShadow++;
-                    trace<CULL, COUNT>(S, F.enableAccelStructure != 0, lpos, sd, t, tri, stack, tc);
-                    const bool expected = fabsf(t - length(p - lpos)) <= 5e-4f;
-                    if (!(tri != kNoHit && expected)) visible = splat(0.0f);
-                }
-                if (type == 0) { // computeContributionPointLight (src/light.cpp:151-159)
-                    Lo = Lo + shade(F, -rd, normalize(lpos - p), visible, hn, m);
-                } else { // the sampled POSITION is handed over as the light direction (src/light.cpp:191, 228)
-                    areaAcc = areaAcc + shade(F, -rd, lpos, visible, hn, m) / (1.0f * F.numShadowSamples);
-                }
+    uint32_t j = 0;
+    for (uint32_t li = 0; li < S.nLights; li++) {
+        const GpuLight& L = S.lights[li];
+        const int type = (int)L.type;
+        const uint32_t nSamples = (type == 0) ? 1u : F.numShadowSamples;
+        for (uint32_t s = 0; s < nSamples; s++, j++) {
+            vec3 lpos, lcol;
+            if (type == 0) {
+                lpos = load3(L.f);
+                lcol = load3(L.f + 3);
+            } else if (type == 1) { // sampleSegmentLight (src/light.cpp:25-29)
+                const float u = sampler_next(smp);
+                const vec3 e0 = load3(L.f), e1 = load3(L.f + 3), c0 = load3(L.f + 6), c1 = load3(L.f + 9);
+                lpos = e0 + u * (e1 - e0);
+                lcol = c0 + u * (c1 - c0);
+            } else { // sampleParallelogramLight (src/light.cpp:40-53)
+                const float sx = sampler_next(smp);
+                const float sy = sampler_next(smp);
+                lpos = load3(L.f) + sx * load3(L.f + 3) + sy * load3(L.f + 6);
+                const float a0 = (1.0f - sx) * (1.0f - sy), a1 = (1.0f - sx) * sy, a2 = sx * (1.0f - sy), a3 = sx * sy;
+                lcol = a0 * load3(L.f + 9) + a1 * load3(L.f + 12) + a2 * load3(L.f + 15) + a3 * load3(L.f + 18);
             }
-            if (type != 0) Lo = Lo + areaAcc;
+            fn(j, type, s + 1 == nSamples, lpos, lcol);
         }
-        accumulate_pixel(P, pixel, W * Lo);
+    }
+}
+
+// Shadow rays of the shade tasks [chunkBase, chunkBase + chunkTasks): visibilityOfLightSampleBinary
+// (src/light.cpp:66-90) traces from the light towards the hit point.
+__global__ __launch_bounds__(kBlock) void shadow_gen_kernel(const WaveParams P)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t have = min(P.qCount[0], P.shadeCap);
+    const uint32_t total = have > P.chunkBase ? min(have - P.chunkBase, P.chunkTasks) : 0u;
+    uint32_t cShadow = 0;
+    TraceCounters tc { 0, 0, 0 };
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const float4* q = reinterpret_cast<const float4*>(P.shadeQ + P.chunkBase + i);
+        const float4 a = q[0], b = q[1], c = q[2];
+        const vec3 p = make3(b.w, c.x, c.y);
+        RayRec* out = P.shadowRays + (size_t)i * P.raysPerTask;
+        for_each_light_sample(P.S, P.F, __float_as_uint(a.z), [&](const uint32_t j, int, bool, const vec3 lpos, const vec3) {
+            store_ray(out + j, lpos, normalize(p - lpos), FLT_MAX, 0u);
+            cShadow++;
+        });
     }
     flush_counters(P.stats, lane, 0, cShadow, 0, tc, 0, 0);
+}
+
+// computeLightContribution (src/light.cpp:262-276) for the shade tasks of the chunk, with the shadow
+// queries answered by P.hits (null when shadows are off).
+__global__ __launch_bounds__(kBlock) void shade_logic_kernel(const WaveParams P)
+{
+    const SceneView& S = P.S;
+    const rt_features& F = P.F;
+    const uint32_t have = min(P.qCount[0], P.shadeCap);
+    const uint32_t total = have > P.chunkBase ? min(have - P.chunkBase, P.chunkTasks) : 0u;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const float4* q = reinterpret_cast<const float4*>(P.shadeQ + P.chunkBase + i);
+        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        const uint32_t pixel = __float_as_uint(a.x), matInfo = __float_as_uint(a.y);
+        const vec3 W = make3(b.x, b.y, b.z), p = make3(b.w, c.x, c.y), rd = make3(c.z, c.w, e.x), hn = make3(e.y, e.z, e.w);
+        const Mat m = load_material(S, matInfo & 0x7fffffffu, (matInfo >> 31) != 0);
+        const HitRec* hits = P.hits ? P.hits + (size_t)i * P.raysPerTask : nullptr;
+        vec3 Lo = splat(0.0f), areaAcc = splat(0.0f);
+        for_each_light_sample(S, F, __float_as_uint(a.z), [&](const uint32_t j, const int type, const bool last, const vec3 lpos, const vec3 lcol) {
+            vec3 visible = lcol;
+            if (hits) {
+                const HitRec h = hits[j];
+                const bool expected = fabsf(h.t - length(p - lpos)) <= 5e-4f;
+                if (!(h.tri != kNoHit && expected)) visible = splat(0.0f);
+            }
+            if (type == 0) { // computeContributionPointLight (src/light.cpp:151-159)
+                Lo = Lo + shade(F, -rd, normalize(lpos - p), visible, hn, m);
+            } else { // the sampled POSITION is handed over as the light direction (src/light.cpp:191, 228)
+                areaAcc = areaAcc + shade(F, -rd, lpos, visible, hn, m) / (1.0f * F.numShadowSamples);
+                if (last) {
+                    Lo = Lo + areaAcc;
+                    areaAcc = splat(0.0f);
+                }
+            }
+        });
+        accumulate_pixel(P, pixel, W * Lo);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,20 @@
+"""Render N frames of a bench workload (no counting pass, no timing) - a target for profilers."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from raytracer_amd import api
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+wl = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "dragon_glossy_bloom"]
+W, H = 1920, 1080
+sc = bench.build_scene_arrays(wl["scene"])
+scene = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+fkw = dict(bench.FEATURE_BASE); fkw.update(wl["feat"])
+feat = api.Features(**fkw)
+cam = api.camera_from_trackball(W, H)
+frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+for _ in range(n):
+    scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), stream=stream)
+torch.cuda.synchronize()
+print("stats", scene.sync(stream).rays if hasattr(scene.sync(stream), "rays") else "ok")
