@@ -45,16 +45,18 @@ struct rt_scene {
     uint32_t shadeCap = 0, leafCap = 0;
     float* d_states = nullptr;      // path-state pool, one slot per pixel of the region
     uint32_t* d_active[2] = { nullptr, nullptr };
+    uint32_t* d_activeRay[2] = { nullptr, nullptr }; // first ray of each active state
+    size_t pathRayCap = 0;
     uint32_t* d_roundCounts = nullptr; // [0, kMaxRounds): active-list size per round; then one work counter per trace launch
     uint32_t stateCap = 0;
-    void* d_pathRays = nullptr;   // stateCap ray records
+    void* d_pathRays[2] = { nullptr, nullptr }; // rays of the even / odd path rounds
     void* d_hits = nullptr;       // hit records of the stage being traced
     size_t hitCap = 0;
     void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
-    uint32_t bulkLanes = 1;  // the same for the deferred leaf and shadow rays (RT_AMD_BULK_LANES overrides)
+    uint32_t laneModeAbove = 131072; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     std::vector<int> lightTypes;
 };
 
@@ -74,8 +76,9 @@ constexpr int kFrameFloats = 20; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
 constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
-constexpr uint32_t kMaxTraceLaunches = kMaxRounds + 1024; // work counters for the trace launches of one frame
+constexpr uint32_t kMaxTraceLaunches = 2 * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
+constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
 enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
 
@@ -274,9 +277,9 @@ __device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t fir
     for (uint32_t k = 0; k < cnt; k += 4) {
         const uint32_t m = cnt - k;
         const float4 p0 = planes[k];
-        const float4 p1 = (m > 1) ? planes[k + 1] : p0;
-        const float4 p2 = (m > 2) ? planes[k + 2] : p0;
-        const float4 p3 = (m > 3) ? planes[k + 3] : p0;
+        const float4 p1 = planes[k + (m > 1 ? 1 : 0)];
+        const float4 p2 = planes[k + (m > 2 ? 2 : 0)];
+        const float4 p3 = planes[k + (m > 3 ? 3 : 0)];
         if (COUNT) tc.triTests += (m > 4 ? 4 : m);
         const float t0 = (p0.w - dot(o, make3(p0.x, p0.y, p0.z))) / dot(d, make3(p0.x, p0.y, p0.z));
         const float t1 = (p1.w - dot(o, make3(p1.x, p1.y, p1.z))) / dot(d, make3(p1.x, p1.y, p1.z));
@@ -301,6 +304,27 @@ __device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t fir
         if (c1 && i1 && t >= t1) t = t1, tri = b + 1;
         if (c2 && i2 && t >= t2) t = t2, tri = b + 2;
         if (c3 && i3 && t >= t3) t = t3, tri = b + 3;
+    }
+}
+
+// The same leaf with one triangle in flight at a time: fewer live registers, for kernels that rely on
+// many resident waves rather than on short steps.
+template <bool COUNT>
+__device__ __forceinline__ void leaf_test_narrow(const SceneView& S, const uint32_t first, const uint32_t cnt, const vec3 o, const vec3 d, float& t,
+                                                 uint32_t& tri, TraceCounters& tc)
+{
+    const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        const uint32_t m = cnt - k; // planes of up to four triangles in flight together
+        const float4 p0 = planes[k];
+        const float4 p1 = planes[k + (m > 1 ? 1 : 0)];
+        const float4 p2 = planes[k + (m > 2 ? 2 : 0)];
+        const float4 p3 = planes[k + (m > 3 ? 3 : 0)];
+        if (COUNT) tc.triTests += (m > 4 ? 4 : m);
+        tri_test_plane(S, first + k, p0, o, d, t, tri);
+        if (m > 1) tri_test_plane(S, first + k + 1, p1, o, d, t, tri);
+        if (m > 2) tri_test_plane(S, first + k + 2, p2, o, d, t, tri);
+        if (m > 3) tri_test_plane(S, first + k + 3, p3, o, d, t, tri);
     }
 }
 
@@ -390,7 +414,7 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
             }
             if (cur == kTraversalDone) break;
             const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
-            leaf_test<COUNT>(S, first, cnt, o, d, t, tri, tc);
+            leaf_test_narrow<COUNT>(S, first, cnt, o, d, t, tri, tc);
             if (sp == 0) break;
             sp--;
             cur = (sp < kStackDepth) ? stack[sp * kBlock] : kLeafBit;
@@ -1281,7 +1305,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.nPairs = uint32_t(nPairs), V.nTris = uint32_t(nTris), V.nMaterials = nMaterials, V.nLights = nLights, V.nSpheres = nSpheres;
     V.fastBounds = flat.fastBounds ? 1u : 0u;
     s->treeDepth = flat.maxDepth;
-    if (const char* e = getenv("RT_AMD_BULK_LANES")) s->bulkLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) s->groupLanes = (uint32_t)atoi(e);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
@@ -1307,8 +1331,11 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_states);
     (void)hipFree(s->d_active[0]);
     (void)hipFree(s->d_active[1]);
+    (void)hipFree(s->d_activeRay[0]);
+    (void)hipFree(s->d_activeRay[1]);
     (void)hipFree(s->d_roundCounts);
-    (void)hipFree(s->d_pathRays);
+    (void)hipFree(s->d_pathRays[0]);
+    (void)hipFree(s->d_pathRays[1]);
     (void)hipFree(s->d_hits);
     (void)hipFree(s->d_shadowRays);
     delete s;
@@ -1402,17 +1429,37 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         RT_HIP(hipMalloc(&scene->d_leafQ, want * sizeof(LeafTask)));
         scene->leafCap = (uint32_t)want;
     }
+    // a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
+    uint32_t batchRays = 0;
+    {
+        bool area = false;
+        for (int ty : scene->lightTypes) area = area || ty != 0;
+        const uint32_t N = features->numGlossySamples;
+        if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && N * (N + 1) / 2 <= kMaxBatchRays
+            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !getenv("RT_AMD_NO_BATCH"))
+            batchRays = N * (N + 1) / 2;
+    }
+    const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
     if (scene->stateCap < nWork) {
         (void)hipFree(scene->d_states), (void)hipFree(scene->d_active[0]), (void)hipFree(scene->d_active[1]);
-        (void)hipFree(scene->d_pathRays);
-        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->d_pathRays = nullptr, scene->stateCap = 0;
+        (void)hipFree(scene->d_activeRay[0]), (void)hipFree(scene->d_activeRay[1]);
+        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->stateCap = 0;
+        scene->d_activeRay[0] = scene->d_activeRay[1] = nullptr;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_states), (size_t)nWork * kStateDwords * sizeof(float)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[0]), (size_t)nWork * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[1]), (size_t)nWork * sizeof(uint32_t)));
-        RT_HIP(hipMalloc(&scene->d_pathRays, (size_t)nWork * sizeof(RayRec)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_activeRay[0]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_activeRay[1]), (size_t)nWork * sizeof(uint32_t)));
         scene->stateCap = nWork;
     }
-    const size_t countWords = kMaxRounds + kMaxTraceLaunches;
+    if (scene->pathRayCap < pathRaysWanted) {
+        (void)hipFree(scene->d_pathRays[0]), (void)hipFree(scene->d_pathRays[1]);
+        scene->d_pathRays[0] = scene->d_pathRays[1] = nullptr, scene->pathRayCap = 0;
+        RT_HIP(hipMalloc(&scene->d_pathRays[0], pathRaysWanted * sizeof(RayRec)));
+        RT_HIP(hipMalloc(&scene->d_pathRays[1], pathRaysWanted * sizeof(RayRec)));
+        scene->pathRayCap = pathRaysWanted;
+    }
+    const size_t countWords = 2 * kMaxRounds + kMaxTraceLaunches;
     if (!scene->d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_roundCounts), countWords * sizeof(uint32_t)));
     // shadow rays: one per point light and numShadowSamples per area light for every shade task, generated and
     // traced in chunks of tasks that fit the shadow-ray buffer
@@ -1442,7 +1489,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         }
     }
     {
-        size_t hitsWanted = nWork;
+        size_t hitsWanted = pathRaysWanted;
         if (hitsWanted < scene->leafCap) hitsWanted = scene->leafCap;
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
         if (scene->hitCap < hitsWanted) {
@@ -1461,7 +1508,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint64_t term = 1;
         chain = 0;
         for (int l = 0; l < levels && chain < kMaxRounds; l++) {
-            chain += term;
+            // the deepest level of a batched frame costs one round per PARENT ray, not one per ray
+            chain += (batchRays && l == levels - 1 && l > 0) ? term / (fan ? fan : 1) : term;
             term *= (fan ? fan : 1);
             if (!features->enableReflections) break;
         }
@@ -1469,7 +1517,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
         chain *= nRays;
     }
-    if (chain > kMaxRounds - 1 || nChunks + 8 > kMaxTraceLaunches - kMaxRounds) {
+    if (chain > kMaxRounds - 1 || 2 * nChunks + 32 > kMaxTraceLaunches - 2 * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
                       (unsigned long long)chain, kMaxRounds - 1, nChunks);
@@ -1492,39 +1540,36 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     P.shadeCap = scene->shadeCap, P.leafCap = scene->leafCap;
     P.lightDraws = lightDraws;
     P.states = scene->d_states;
-    P.pathRays = static_cast<RayRec*>(scene->d_pathRays);
+    P.pathRays = static_cast<RayRec*>(scene->d_pathRays[0]), P.pathRaysIn = nullptr;
+    P.rayCap = (uint32_t)(scene->pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : scene->pathRayCap);
+    P.batchRays = batchRays;
     P.hits = static_cast<const HitRec*>(scene->d_hits);
     P.shadowRays = static_cast<RayRec*>(scene->d_shadowRays);
     P.chunkBase = 0, P.chunkTasks = chunkTasks, P.raysPerTask = raysPerTask;
     const uint32_t taskGrid = (uint32_t)scene->numCUs * 8u;
     uint32_t resolveGrid = fullGrid < taskGrid ? fullGrid : taskGrid;
-    const uint32_t rounds = (uint32_t)chain - 1; // after the camera-ray round
+    const uint32_t rounds = (uint32_t)chain; // the camera rays are the first round
 
     TraceParams T;
     T.S = scene->view;
     T.hits = static_cast<HitRec*>(scene->d_hits);
     T.stats = scene->d_stats;
     T.useBvh = features->enableAccelStructure ? 1u : 0u;
-    uint32_t nextFetch = kMaxRounds;
+    uint32_t nextFetch = 2 * kMaxRounds;
+    uint32_t* const rayCounts = scene->d_roundCounts + kMaxRounds;
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
     const uint32_t traceGrid = (uint32_t)scene->numCUs * 8u;
-    const bool groupOk = features->enableAccelStructure && scene->treeDepth <= 30;
-    const int reserve = (int)scene->treeDepth + 2;
-    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul,
-                            uint32_t groupLanes) {
-        T.rays = static_cast<const char*>(rays), T.rayStride = stride;
-        T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
+    const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
+    auto launch_one = [&](uint32_t groupLanes) {
         T.fetch = scene->d_roundCounts + nextFetch++;
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
     do {                                                                                                                  \
-        if (groupOk && groupLanes == 4)                                                                                   \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
-        else if (groupOk && groupLanes == 8)                                                                              \
+        if (groupLanes == 8)                                                                                              \
             hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
-        else if (groupOk && groupLanes == 16)                                                                             \
+        else if (groupLanes == 16)                                                                                        \
             hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
-        else if (groupOk && groupLanes == 32)                                                                             \
+        else if (groupLanes == 32)                                                                                        \
             hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
         else if (stackClass == 0) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
         else if (stackClass == 1) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 24>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
@@ -1536,27 +1581,44 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         else RT_TRACE_CASE(false, true);
 #undef RT_TRACE_CASE
     };
+    // One stage of closest-hit queries.  Many rays: one ray per lane (throughput).  Few rays: several lanes per
+    // ray, which shortens the stage's slowest ray.  The ray count is only known on the device, so both variants
+    // are launched and the one whose range does not hold the count returns at once.
+    const bool groupOk = features->enableAccelStructure && scene->treeDepth <= 30 && scene->groupLanes > 1;
+    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
+        T.rays = static_cast<const char*>(rays), T.rayStride = stride;
+        T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
+        T.runLo = 0, T.runHi = 0xffffffffu;
+        if (!groupOk) {
+            launch_one(1);
+            return;
+        }
+        T.runLo = scene->laneModeAbove;
+        launch_one(1);
+        T.runLo = 0, T.runHi = scene->laneModeAbove;
+        launch_one(scene->groupLanes);
+    };
 
     P.activeIn = nullptr, P.activeInCount = nullptr;
     P.activeOut = scene->d_active[0], P.activeOutCount = scene->d_roundCounts;
-    if (cull && !count) hipLaunchKernelGGL((primary_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, P);
-    else if (cull && count) hipLaunchKernelGGL((primary_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, P);
-    else if (!cull && !count) hipLaunchKernelGGL((primary_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, P);
-    else hipLaunchKernelGGL((primary_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, P);
+    P.activeRayIn = nullptr, P.activeRayOut = scene->d_activeRay[0], P.rayCountOut = rayCounts;
+    hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
     for (uint32_t r = 1; r <= rounds; r++) {
-        launch_trace(scene->d_pathRays, sizeof(RayRec), scene->d_roundCounts + (r - 1), 0, nWork, 1, scene->groupLanes);
+        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), rayCounts + (r - 1), 0, P.rayCap, 1);
+        P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
         P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
         P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;
+        P.activeRayIn = scene->d_activeRay[(r - 1) & 1], P.activeRayOut = scene->d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
         hipLaunchKernelGGL(path_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     }
-    launch_trace(scene->d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, scene->leafCap, 1, scene->bulkLanes);
+    launch_trace(scene->d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, scene->leafCap, 1);
     hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     for (uint32_t c = 0; c < nChunks; c++) {
         P.chunkBase = c * chunkTasks;
         P.chunkTasks = (scene->shadeCap - P.chunkBase < chunkTasks) ? scene->shadeCap - P.chunkBase : chunkTasks;
         if (shadows) {
             hipLaunchKernelGGL(shadow_gen_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-            launch_trace(scene->d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask, scene->bulkLanes);
+            launch_trace(scene->d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
             P.hits = static_cast<const HitRec*>(scene->d_hits);
         } else {
             P.hits = nullptr;

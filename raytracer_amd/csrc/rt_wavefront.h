@@ -78,7 +78,13 @@ struct WaveParams {
     uint32_t* activeOut;      // survivors
     const uint32_t* activeInCount;
     uint32_t* activeOutCount;
-    RayRec* pathRays;         // ray of activeOut[i] for the next round
+    RayRec* pathRays;         // rays of the next round; activeRayOut[i] = first ray of state activeOut[i]
+    const RayRec* pathRaysIn; // rays of the round whose hits this kernel consumes (a different buffer)
+    uint32_t* rayCountOut;    // rays appended for the next round
+    const uint32_t* activeRayIn;
+    uint32_t* activeRayOut;
+    uint32_t rayCap;          // capacity of pathRays
+    uint32_t batchRays;       // N(N+1)/2 candidate rays of a batched glossy loop (0 = loops are walked one child per round)
     const HitRec* hits;       // hits of the rays this kernel consumes
     RayRec* shadowRays;       // shadow_gen output, raysPerTask per shade task of the chunk
     uint32_t chunkBase, chunkTasks, raysPerTask;
@@ -166,6 +172,7 @@ struct TraceParams {
     const uint32_t* countPtr; // number of items = clamp(*countPtr - countSub, 0, countMaxItems) * countMul
     uint32_t countSub, countMaxItems, countMul;
     uint32_t rayStride;       // bytes between ray records
+    uint32_t runLo, runHi;    // the launch does nothing unless runLo <= number of rays < runHi (several variants share one ray list)
     uint32_t* fetch;          // zeroed work counter of this launch
     unsigned long long* stats;
     uint32_t useBvh;
@@ -239,7 +246,7 @@ __device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uin
         }
     } else {
         const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
-        leaf_test<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
+        leaf_test_narrow<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
         pop = true;
     }
     if (pop) {
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
     const uint32_t have = *P.countPtr;
     const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
     const uint32_t total = items * P.countMul;
+    if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
     bool has = false, exhausted = false;
     uint32_t idx = 0;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
 // ---------------------------------------------------------------------------------------------
 constexpr int kFrameDwords = 20;                                   // 80 B per pending glossy loop
 constexpr int kStateDwords = 16 + RT_MAX_RAY_DEPTH * kFrameDwords; // 544 B
-enum PathStep : int { PS_DONE = 0, PS_TRACE = 1, PS_HIT, PS_GLOSSY, PS_POP };
+enum PathStep : int { PS_DONE = 0, PS_TRACE = 1, PS_HIT, PS_GLOSSY, PS_POP, PS_BATCH };
 
 struct PathLane {
     // header
@@ -332,7 +340,9 @@ struct PathLane {
     vec3 to, td, curW;
     int depth, loopDepth; // rayDepth of the ray in flight; rayDepth of the innermost pending glossy loop (-1: none)
     uint32_t sampleIdx;
+    uint32_t nRays;   // rays in flight for this state: 1, or batchRays for a batched glossy loop
     // working
+    uint32_t rayBase; // first of those rays / hits
     float tt;
     uint32_t ttri;
     int state;
@@ -346,6 +356,7 @@ __device__ __forceinline__ void load_header(const float* s, PathLane& L)
     L.to = make3(b.x, b.y, b.z), L.td = make3(b.w, c.x, c.y), L.curW = make3(c.z, c.w, d.x);
     const uint32_t pk = __float_as_uint(d.y);
     L.depth = (int)(pk & 0xffu), L.loopDepth = (int)((pk >> 8) & 0xffu) - 1, L.sampleIdx = pk >> 16;
+    L.nRays = __float_as_uint(d.z);
 }
 __device__ __forceinline__ void store_header(float* s, const PathLane& L)
 {
@@ -354,7 +365,7 @@ __device__ __forceinline__ void store_header(float* s, const PathLane& L)
     q[0] = make_float4(__uint_as_float(L.pixel), __uint_as_float(L.smp), __uint_as_float(L.seed), __uint_as_float(L.pxy));
     q[1] = make_float4(L.to.x, L.to.y, L.to.z, L.td.x);
     q[2] = make_float4(L.td.y, L.td.z, L.curW.x, L.curW.y);
-    q[3] = make_float4(L.curW.z, __uint_as_float(pk), 0.0f, 0.0f);
+    q[3] = make_float4(L.curW.z, __uint_as_float(pk), __uint_as_float(L.nRays), 0.0f);
 }
 
 __device__ __forceinline__ uint32_t pixel_ray_count(const rt_features& F)
@@ -392,7 +403,56 @@ __device__ __forceinline__ void make_pixel_ray(const WaveParams& P, PathLane& L,
     L.depth = P.startDepth;
     L.loopDepth = -1;
     L.sampleIdx = k;
+    L.nRays = 1;
 }
+
+// Reserves `n` consecutive slots of a queue for every lane with n > 0: one atomic per wave.  Returns the
+// lane's first slot (0xffffffff when the reservation does not fit the queue: nothing may be written then).
+__device__ __forceinline__ uint32_t reserve_slots(uint32_t* count, const uint32_t cap, const uint32_t n, const int lane)
+{
+    uint32_t incl = n; // inclusive prefix sum over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) return 0xffffffffu;
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(count, total);
+    base = __shfl(base, 63);
+    const uint32_t first = base + incl - n;
+    return (n != 0 && first + n <= cap) ? first : 0xffffffffu;
+}
+
+// One sample of renderRayGlossyComponent's loop (src/extra.cpp:489-505): sampleDisk (src/extra.cpp:443-450)
+// draws twice from `smp`; false when the perturbed direction points into the surface.
+__device__ __forceinline__ bool glossy_sample(uint32_t& smp, const float radius, const vec3 w, const vec3 u, const vec3 v, const vec3 nrm, vec3& pd)
+{
+    const float r = radius * sqrtf(sampler_next(smp));
+    const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
+    const float dx = r * cosf(angle), dy = r * sinf(angle);
+    pd = normalize(w + dx * u + dy * v);
+    return !(dot(pd, nrm) <= 0);
+}
+
+__device__ __forceinline__ void store_shade_task(ShadeTask* q, const uint32_t pixel, const uint32_t matInfo, const uint32_t smp, const vec3 W,
+                                                 const vec3 p, const vec3 d, const vec3 n)
+{
+    float4* o = reinterpret_cast<float4*>(q);
+    o[0] = make_float4(__uint_as_float(pixel), __uint_as_float(matInfo), __uint_as_float(smp), 0.0f);
+    o[1] = make_float4(W.x, W.y, W.z, p.x);
+    o[2] = make_float4(p.y, p.z, d.x, d.y);
+    o[3] = make_float4(d.z, n.x, n.y, n.z);
+}
+__device__ __forceinline__ void store_leaf_task(LeafTask* q, const uint32_t pixel, const vec3 o, const vec3 d, const float tmax, const vec3 W)
+{
+    float4* out = reinterpret_cast<float4*>(q);
+    out[0] = make_float4(o.x, o.y, o.z, tmax);
+    out[1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+    out[2] = make_float4(W.x, W.y, W.z, 0.0f);
+}
+constexpr uint32_t kHolePixel = 0xffffffffu; // a reserved but unused ShadeTask slot
 
 // Advances every lane from "its ray has been traced" (PS_HIT) to its next ray (PS_TRACE) or the end
 // of its pixel (PS_DONE), appending the shade / leaf tasks met on the way.  Wave-convergent.
@@ -408,8 +468,8 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
     ShadeTask st;
     LeafTask lt;
     do {
-        bool wantShade = false, wantLeaf = false, wantFrames = false;
-        while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames) {
+        bool wantShade = false, wantLeaf = false, wantFrames = false, wantBatch = false, wantConsume = false;
+        while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames && !wantBatch && !wantConsume) {
             switch (L.state) {
             case PS_HIT: {
                 // renderRay after the intersection (src/recursive.cpp:29-36, 62-80)
@@ -471,6 +531,10 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
                 vec3 w, u, v;
                 ortho_basis(rdir, w, u, v);
+                if (P.batchRays != 0 && i == 0 && L.loopDepth == RT_MAX_RAY_DEPTH - 2) {
+                    wantBatch = true; // emitted below, once the wave has reserved the rays
+                    break;
+                }
                 bool launched = false;
                 while (i < F.numGlossySamples) {
                     // sampleDisk (src/extra.cpp:443-450): two draws per sample, consumed even if rejected
@@ -522,6 +586,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 }
                 break;
             }
+            case PS_BATCH: wantConsume = true; break;
             default: L.state = PS_DONE; break;
             }
         }
@@ -547,25 +612,120 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         if (__ballot(wantLeaf) != 0ull) {
             if (!queue_append(P.leafQ, P.qCount + 1, P.leafCap, wantLeaf, lt, lane)) cDrop++;
         }
+        // ---- batched glossy loop: the loop's children are the last rays that can spawn anything, and each of
+        // them either consumes no further draws or exactly 2N (its own loop, whose children are deferred).  Child
+        // i therefore starts at one of i+1 known sampler offsets: trace a candidate for each, pick afterwards.
+        if (__ballot(wantBatch) != 0ull) {
+            const uint32_t N = F.numGlossySamples;
+            const uint32_t base = reserve_slots(P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane);
+            if (wantBatch) {
+                if (base == 0xffffffffu) {
+                    cDrop++;
+                    L.state = PS_DONE;
+                } else {
+                    const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * kFrameDwords);
+                    const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
+                    const vec3 rorg = make3(f0.w, f1.x, f1.y), rdir = make3(f1.z, f1.w, f2.x), nrm = make3(f2.y, f2.z, f2.w);
+                    const float radius = f3.w;
+                    vec3 w, u, v;
+                    ortho_basis(rdir, w, u, v);
+                    uint32_t rowSmp = L.smp; // offset 2i: no earlier child consumed anything
+                    uint32_t k = 0;
+                    for (uint32_t i = 0; i < N; i++) {
+                        uint32_t candSmp = rowSmp;
+                        for (uint32_t c = 0; c <= i; c++, k++) {
+                            uint32_t s2 = candSmp;
+                            vec3 pd;
+                            if (glossy_sample(s2, radius, w, u, v, nrm, pd)) store_ray(P.pathRays + base + k, rorg + 0.0001f * pd, pd, FLT_MAX, 0u);
+                            else store_ray(P.pathRays + base + k, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, 0u); // no ray: misses at once
+                            for (uint32_t z = 0; z < 2 * N; z++) (void)sampler_next(candSmp); // one more earlier child with a loop of its own
+                        }
+                        (void)sampler_next(rowSmp);
+                        (void)sampler_next(rowSmp);
+                    }
+                    L.nRays = P.batchRays;
+                    L.rayBase = base;
+                    L.state = PS_TRACE;
+                }
+            }
+        }
+        if (__ballot(wantConsume) != 0ull) {
+            // the traced candidates are back: walk the loop in the reference's order
+            const uint32_t N = F.numGlossySamples;
+            const uint32_t shadeBase = reserve_slots(P.qCount + 0, P.shadeCap, wantConsume ? N : 0u, lane);
+            const uint32_t leafBase = reserve_slots(P.qCount + 1, P.leafCap, wantConsume ? N * N : 0u, lane);
+            if (wantConsume) {
+                const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * kFrameDwords);
+                const float4 f0 = fq[0], f3 = fq[3], f4 = fq[4];
+                const vec3 fW = make3(f0.x, f0.y, f0.z), ks = make3(f3.x, f3.y, f3.z);
+                const int enclosing = (int)__float_as_uint(f4.y) - 1;
+                const vec3 cw = fW * ks / float(N);
+                uint32_t hitsSoFar = 0, nShade = 0, nLeaf = 0;
+                const bool room = shadeBase != 0xffffffffu && leafBase != 0xffffffffu;
+                if (!room) cDrop++;
+                for (uint32_t i = 0; i < N; i++) {
+                    (void)sampler_next(L.smp); // the sample's own two draws (its direction is in the stored ray)
+                    (void)sampler_next(L.smp);
+                    const uint32_t k = i * (i + 1) / 2 + hitsSoFar;
+                    const float4* rq = reinterpret_cast<const float4*>(P.pathRaysIn + L.rayBase + k);
+                    const float4 ra = rq[0], rb = rq[1];
+                    if (ra.w < 0.0f) continue; // rejected sample
+                    cSecondary++;
+                    const HitRec hr = P.hits[L.rayBase + k];
+                    if (hr.tri == kNoHit) continue;
+                    const vec3 co = make3(ra.x, ra.y, ra.z), cd = make3(rb.x, rb.y, rb.z);
+                    Hit h;
+                    fill_hit(S, F, hr.tri, co, cd, hr.t, h);
+                    const vec3 p = co + hr.t * cd;
+                    if (room) store_shade_task(P.shadeQ + shadeBase + nShade, L.pixel, h.mesh | (h.isSphere ? 0x80000000u : 0u), L.smp, cw, p, cd, h.normal);
+                    nShade++;
+                    if (!F.enableReflections) continue;
+                    const Mat m = load_material(S, h.mesh, h.isSphere);
+                    if (!((m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f))) continue;
+                    // the child's own glossy loop: its children sit at the recursion limit
+                    vec3 rorg = p;
+                    const vec3 rdir = cd - 2.f * dot(cd, h.normal) * h.normal;
+                    rorg = rorg + 0.00001f * rdir;
+                    const float radius = 0.5f / m.shininess;
+                    vec3 w, u, v;
+                    ortho_basis(rdir, w, u, v);
+                    const vec3 lw = cw * m.ks / float(N);
+                    for (uint32_t s2 = 0; s2 < N; s2++) {
+                        vec3 pd;
+                        if (!glossy_sample(L.smp, radius, w, u, v, h.normal, pd)) continue;
+                        cSecondary++;
+                        if (room) store_leaf_task(P.leafQ + leafBase + nLeaf, L.pixel, rorg + 0.0001f * pd, pd, FLT_MAX, lw);
+                        nLeaf++;
+                    }
+                    hitsSoFar++;
+                }
+                if (room) { // unused reserved slots stay in the queues as holes
+                    for (uint32_t z = nShade; z < N; z++) reinterpret_cast<float4*>(P.shadeQ + shadeBase + z)[0] = make_float4(__uint_as_float(kHolePixel), 0.0f, 0.0f, 0.0f);
+                    for (uint32_t z = nLeaf; z < N * N; z++) store_leaf_task(P.leafQ + leafBase + z, kHolePixel, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, splat(0.0f));
+                }
+                L.nRays = 1;
+                L.loopDepth = enclosing;
+                L.state = PS_POP;
+            }
+        }
     } while (__ballot(L.state > PS_TRACE) != 0ull);
 }
 
-// Round 0: camera rays.  Persistent lanes fetch pixels (8x8 tiles in fetch order) until none are left.
-template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(kBlock) void primary_kernel(const WaveParams P)
+// Round 0: camera rays.  Most pixels of a frame look past the scene: only a pixel whose ray enters the root
+// box (or that has further pixel samples to take) gets a recursion state and a ray to trace.
+__global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_stack[kStackDepth * kBlock];
-    uint32_t* const stack = s_stack + threadIdx.x;
+    __shared__ uint32_t s_n[4], s_base;
     const rt_features& F = P.F;
     const int lane = threadIdx.x & 63;
     const uint32_t nPixelRays = pixel_ray_count(F);
-    uint32_t cPrimary = 0, cSecondary = 0, cPixels = 0, cDrop = 0;
+    uint32_t cPrimary = 0, cPixels = 0, cDrop = 0;
     TraceCounters tc { 0, 0, 0 };
-    for (;;) {
-        const uint32_t w = wave_fetch(P.work + 0, true, lane);
-        if (__ballot(w < P.nWork) == 0ull) break;
+    for (uint32_t base = blockIdx.x * kBlock; base < P.nWork; base += gridDim.x * kBlock) { // block-uniform trip count
+        const uint32_t w = base + threadIdx.x;
         PathLane L;
         L.state = PS_DONE;
+        L.nRays = 1, L.rayBase = 0;
         if (w < P.nWork) {
             const uint32_t tile = w >> 6, l = w & 63;
             const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
@@ -583,32 +743,42 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(const WaveParams P)
                 if (P.primT) P.primT[py * P.W + px] = FLT_MAX;
                 make_pixel_ray(P, L, 0, nPixelRays);
                 cPrimary++;
-                L.tt = FLT_MAX;
-                trace<CULL, COUNT>(P.S, F.enableAccelStructure != 0, L.to, L.td, L.tt, L.ttri, stack, tc);
-                L.state = PS_HIT;
+                bool live = nPixelRays > 1 || !F.enableAccelStructure;
+                if (!live) { // the root test every query starts with (src/bvh.cpp:264-268)
+                    const RaySlabs R = make_slabs(P.S, L.to, L.td);
+                    float tr;
+                    bool outside;
+                    live = box_test_any(P.S.rootLo[0], P.S.rootLo[1], P.S.rootLo[2], P.S.rootHi[0], P.S.rootHi[1], P.S.rootHi[2], R, FLT_MAX, tr,
+                                        outside);
+                }
+                if (live) L.state = PS_TRACE;
             }
         }
-        float* frames = nullptr;
-        uint32_t slot = 0xffffffffu;
-        auto alloc = [&](const bool need) {
-            const uint32_t s = wave_fetch(P.qCount + 2, need, lane);
-            if (need) {
-                slot = s;
-                frames = P.states + (size_t)s * kStateDwords + 16;
-            }
-        };
-        advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
-        // pixels that still have a ray to trace become active states of round 1
+        // one counter update per workgroup: state slot = ray slot = position in the first active list
         const bool active = (L.state == PS_TRACE);
-        if (__ballot(active && slot == 0xffffffffu) != 0ull) alloc(active && slot == 0xffffffffu);
-        const uint32_t pos = wave_fetch(P.activeOutCount, active, lane);
+        const unsigned long long mask = __ballot(active);
+        const int wv = threadIdx.x >> 6;
+        if (lane == 0) s_n[wv] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            s_base = n ? atomicAdd(P.activeOutCount, n) : 0u;
+            if (n) atomicAdd(P.rayCountOut, n);
+        }
+        __syncthreads();
+        uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wv; k++) pos += s_n[k];
+        __syncthreads();
         if (active) {
-            store_header(P.states + (size_t)slot * kStateDwords, L);
-            P.activeOut[pos] = slot;
-            store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
+            L.rayBase = pos;
+            if (pos < P.rayCap) store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
+            else cDrop++;
+            store_header(P.states + (size_t)pos * kStateDwords, L);
+            P.activeOut[pos] = pos;
+            P.activeRayOut[pos] = pos;
         }
     }
-    flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, cPixels, cDrop);
+    flush_counters(P.stats, lane, cPrimary, 0, 0, tc, cPixels, cDrop);
 }
 
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
@@ -622,6 +792,7 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
         const uint32_t i = base + threadIdx.x;
         PathLane L;
         L.state = PS_DONE;
+        L.nRays = 1, L.rayBase = 0;
         float* frames = nullptr;
         uint32_t slot = 0;
         if (i < total) {
@@ -629,19 +800,32 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
             float* s = P.states + (size_t)slot * kStateDwords;
             load_header(s, L);
             frames = s + 16;
-            const HitRec h = P.hits[i];
-            L.tt = h.t;
-            L.ttri = h.tri;
-            L.state = PS_HIT;
+            L.rayBase = P.activeRayIn[i];
+            if (L.nRays > 1) {
+                L.state = PS_BATCH;
+            } else {
+                const HitRec h = P.hits[L.rayBase];
+                L.tt = h.t;
+                L.ttri = h.tri;
+                L.state = PS_HIT;
+            }
         }
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
         advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
         const bool active = (L.state == PS_TRACE);
         const uint32_t pos = wave_fetch(P.activeOutCount, active, lane);
+        const bool single = active && L.nRays <= 1;
+        const uint32_t rpos = wave_fetch(P.rayCountOut, single, lane); // a batch reserved its rays when it was emitted
+        if (single) {
+            L.nRays = 1;
+            L.rayBase = rpos;
+            if (rpos < P.rayCap) store_ray(P.pathRays + rpos, L.to, L.td, FLT_MAX, 0u);
+            else cDrop++;
+        }
         if (active) {
             store_header(P.states + (size_t)slot * kStateDwords, L);
             P.activeOut[pos] = slot;
-            store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
+            P.activeRayOut[pos] = L.rayBase;
         }
     }
     flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
@@ -792,7 +976,7 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
                                                 const int reserve, const bool active, TraceCounters& tc)
 {
     using Lay = GroupLayout<G>;
-    constexpr uint32_t kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+    constexpr uint32_t kGroupMask = (uint32_t)((1ull << G) - 1ull);
     uint32_t* const lq = q + Lay::kNodeWords;
     int n = T.nq < G ? T.nq : G;
     const int room = Lay::kQ - reserve - T.nq;
@@ -923,6 +1107,7 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
     const uint32_t have = *P.countPtr;
     const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
     const uint32_t total = items * P.countMul;
+    if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
     bool has = false, exhausted = false; // has: same on every lane of a group
     uint32_t idx = 0;
@@ -1054,6 +1239,10 @@ __global__ __launch_bounds__(kBlock) void shadow_gen_kernel(const WaveParams P)
         const float4 a = q[0], b = q[1], c = q[2];
         const vec3 p = make3(b.w, c.x, c.y);
         RayRec* out = P.shadowRays + (size_t)i * P.raysPerTask;
+        if (__float_as_uint(a.x) == kHolePixel) { // unused slot: rays that miss at once
+            for (uint32_t j = 0; j < P.raysPerTask; j++) store_ray(out + j, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, 0u);
+            continue;
+        }
         for_each_light_sample(P.S, P.F, __float_as_uint(a.z), [&](const uint32_t j, int, bool, const vec3 lpos, const vec3) {
             store_ray(out + j, lpos, normalize(p - lpos), FLT_MAX, 0u);
             cShadow++;
@@ -1074,6 +1263,7 @@ __global__ __launch_bounds__(kBlock) void shade_logic_kernel(const WaveParams P)
         const float4* q = reinterpret_cast<const float4*>(P.shadeQ + P.chunkBase + i);
         const float4 a = q[0], b = q[1], c = q[2], e = q[3];
         const uint32_t pixel = __float_as_uint(a.x), matInfo = __float_as_uint(a.y);
+        if (pixel == kHolePixel) continue;
         const vec3 W = make3(b.x, b.y, b.z), p = make3(b.w, c.x, c.y), rd = make3(c.z, c.w, e.x), hn = make3(e.y, e.z, e.w);
         const Mat m = load_material(S, matInfo & 0x7fffffffu, (matInfo >> 31) != 0);
         const HitRec* hits = P.hits ? P.hits + (size_t)i * P.raysPerTask : nullptr;
