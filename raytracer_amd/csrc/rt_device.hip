@@ -1081,7 +1081,8 @@ __global__ __launch_bounds__(kBloomColX * 4) void bloom_cols_kernel(const BloomP
 }
 
 // Self-test of div_by against IEEE division on random and edge-case operands of the range in which
-// the traversal uses it.  counts[0] += mismatching results, counts[1] += cases checked.
+// the traversal uses it.  counts[0] += mismatching results, counts[1] += cases checked; counts[4..] keep the operands
+// and results of the first 16 mismatches.
 __global__ __launch_bounds__(kBlock) void division_selftest_kernel(const uint32_t seed, const uint32_t perThread, unsigned long long* counts)
 {
     uint32_t s = seed ^ (blockIdx.x * kBlock + threadIdx.x) * 2654435761u;
@@ -1436,7 +1437,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
         if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && N * (N + 1) / 2 <= kMaxBatchRays
-            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !getenv("RT_AMD_NO_BATCH"))
+            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !getenv("RT_AMD_NO_BATCH")) // a counting pass walks only the reference's rays
             batchRays = N * (N + 1) / 2;
     }
     const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
@@ -1752,15 +1753,15 @@ int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked)
     }
     unsigned long long h[64] = { 0 };
     if (e == hipSuccess) e = hipMemcpy(h, d, 512, hipMemcpyDeviceToHost);
-    if (getenv("RT_AMD_DEBUG_DIV"))
-        for (int i = 0; i < 16 && i < (int)h[2]; i++)
-            fprintf(stderr, "div mismatch a=%08x d=%08x want=%08x got=%08x\n", (unsigned)(h[4 + 2 * i] >> 32), (unsigned)h[4 + 2 * i], (unsigned)(h[5 + 2 * i] >> 32), (unsigned)h[5 + 2 * i]);
     (void)hipFree(d);
     if (e != hipSuccess) {
         rt::set_error("rt_selftest_division: %s", hipGetErrorString(e));
         return RT_ERR_HIP;
     }
     *mismatches = h[0], *checked = h[1];
+    if (h[0]) // rt_last_error names the first mismatching operands (the call itself still succeeds)
+        rt::set_error("rt_selftest_division: %llu mismatches, first: a=%08x d=%08x a/d=%08x reciprocal form=%08x", h[0],
+                      (unsigned)(h[4] >> 32), (unsigned)h[4], (unsigned)(h[5] >> 32), (unsigned)h[5]);
     return RT_OK;
 }
 

@@ -1,0 +1,44 @@
+"""Row-stripe partition of a frame over ranks, and the gather that reassembles it.
+
+The frame is cut into stripes of `stripe_rows` image rows; stripe s belongs to rank s % world (the same
+rule rt_render applies to an rt_region).  Pixels are independent in the reference's render loop
+(src/render.cpp:27-44), so the ranks exchange nothing while rendering; the only exchange is this
+all-gather of finished stripes (RCCL on GPUs, gloo in the CPU tests).  Bloom needs the whole frame
+(its filter reaches 2F rows up and down, src/extra.cpp:330-416) and runs after the gather.
+
+Frames are in Screen order: memory row m holds image row H-1-m (src/screen.cpp:119-122), so image
+stripe s is memory row block n_stripes-1-s when H is a multiple of stripe_rows.
+"""
+import torch
+
+
+class StripePlan:
+    def __init__(self, height: int, width: int, rank: int, world: int, stripe_rows: int = 8, channels: int = 3,
+                 device="cpu", dtype=torch.float32):
+        if height % stripe_rows:
+            raise ValueError(f"height {height} must be a multiple of the {stripe_rows}-row stripe")
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world of {world}")
+        self.rank, self.world = rank, world
+        self.n_stripes = height // stripe_rows
+        self.per_rank = (self.n_stripes + world - 1) // world
+        self.block = stripe_rows * width * channels
+        self.mine = torch.arange(rank, self.n_stripes, world, device=device)            # image stripes of this rank
+        self.my_blocks = self.n_stripes - 1 - self.mine                                 # their memory row blocks
+        # recv[r, k] is stripe k*world + r; padded slots (beyond n_stripes) are dropped after the gather
+        order = torch.arange(self.per_rank * world, device=device)
+        self.all_blocks = (self.n_stripes - 1 - order.clamp(max=self.n_stripes - 1))[: self.n_stripes]
+        self.send = torch.zeros((self.per_rank, self.block), dtype=dtype, device=device)
+        self.recv = torch.zeros((world, self.per_rank, self.block), dtype=dtype, device=device)
+
+    def owner(self, image_row: int, stripe_rows: int = 8) -> int:
+        return (image_row // stripe_rows) % self.world
+
+    def gather(self, frame: torch.Tensor, dist) -> None:
+        """frame: (H, W, C) Screen-order tensor holding this rank's stripes; on return it holds all of them."""
+        if self.world == 1:
+            return
+        blocks = frame.view(self.n_stripes, self.block)
+        self.send[: len(self.mine)] = blocks[self.my_blocks]
+        dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+        blocks[self.all_blocks] = self.recv.permute(1, 0, 2).reshape(self.per_rank * self.world, -1)[: self.n_stripes]

@@ -317,3 +317,27 @@ def test_error_reporting():
     with pytest.raises(api.RtError) as e:
         g.render_image(cg, fg2, 64, 64, start_depth=7)
     assert e.value.code == api.RT_ERR_INVALID
+
+
+def test_headline_config_at_full_size():
+    """BASELINE's metric configuration itself: dragon stand-in (87,000 triangles), 1920x1080, glossy x4,
+    4 bounces, bloom - against the oracle's frame, plus properties that do not depend on the oracle:
+    the striped render of two ranks reassembles the frame exactly, and a second render repeats it bit for bit."""
+    sc = scenes.dragon_standin()
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    W, H = 1920, 1080
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=4, enableBloomEffect=1)
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    ro["rgb"] = O.bloom(ro["rgb"], fo.bloomFilterSize, fo.bloomFilterThreshold, fo.bloomFilterIntensity)
+    compare_frames(rg, ro, "dragon stand-in 1080p glossy x4 + bloom")
+    gs, os_ = rg["stats"], ro["stats"]
+    got = (gs.primaryRays, gs.shadowRays, gs.secondaryRays)
+    want = (os_["primary"], os_["shadow"], os_["secondary"])
+    print("headline rays", got, want)
+    for a, b in zip(got, want):
+        assert abs(a - b) <= max(1, 1e-4 * b), (got, want)
+    again = g.render_image(cg, fg, W, H, start_depth=2)
+    assert np.array_equal(again["rgb"].view(np.uint32), rg["rgb"].view(np.uint32))

@@ -1,0 +1,21 @@
+"""profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh.
+
+HBM bytes of ONE rt_render launch (all its kernels): rocprofv3 reports both counters in KiB per dispatch;
+reads are doubled as prescribed for gfx950 (FETCH_SIZE tallies 128-byte requests at 64 bytes)."""
+import collections, csv, json, sys
+tag = sys.argv[1]
+frames = 2  # tools/frame.py 2
+def total(path):
+    t = 0.0
+    for r in csv.DictReader(open(path)):
+        if "rocclr" in r["Kernel_Name"] or "at::native" in r["Kernel_Name"]:
+            continue
+        t += float(r["Counter_Value"])
+    return t
+fetch = total(f"gpurun_out/{tag}/pmc_fetch.csv") * 1024 / frames
+write = total(f"gpurun_out/{tag}/pmc_write.csv") * 1024 / frames
+out = {"dragon_glossy_bloom": 2 * fetch + write,
+       "_detail": {"FETCH_SIZE_bytes_per_launch_raw": fetch, "read_correction": 2.0, "WRITE_SIZE_bytes_per_launch": write,
+                   "source": f"profiles/{tag}_pmc_fetch.csv, profiles/{tag}_pmc_write.csv (separate rocprofv3 --pmc passes over tools/frame.py 2)"}}
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print(out)
