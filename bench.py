@@ -35,11 +35,17 @@ WORKLOADS = {
     "teapot_monkey_phong": dict(scene="teapot+monkey", feat=dict(), start_depth=2,
                                 desc="teapot + monkey 1080p, Phong + shadows + mirror reflections, 4 bounces"),
     "cornell_mirror": dict(scene="cornell", feat=dict(), start_depth=4, desc="CornellBox-Mirror-Rotated, 2 bounces"),
+    # one step = one frame of an orbit: camera rotation.y = 20 + 360 * k / steps degrees (other fields default)
+    "dragon_4k_orbit": dict(scene="dragon", feat=dict(enableGlossyReflection=1, numGlossySamples=4, enableBloomEffect=1),
+                            start_depth=2, width=3840, height=2160, orbit=True,
+                            desc="dragon stand-in 3840x2160 camera sweep, Phong + shadows, glossy x4, 4 bounces, bloom F=15"),
 }
 
 
-def build_scene_arrays(name):
+def build_scene_arrays(name, obj=None):
     from raytracer_amd import scenes
+    if obj and name == "dragon":  # the real data/dragon.obj (or any other mesh) in place of the stand-in
+        return scenes.load_obj(obj)
     if name == "dragon":
         return scenes.dragon_standin()
     if name == "teapot+monkey":
@@ -84,8 +90,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="dragon_glossy_bloom", choices=sorted(WORKLOADS))
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=0, help="default: the workload's (1920 unless it says otherwise)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--obj", default=None, help="Wavefront OBJ to use where a workload names the dragon")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cull", action="store_true", help="traverse exactly as the reference (no distance culling)")
     args = ap.parse_args()
@@ -108,15 +115,18 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     wl = WORKLOADS[args.workload]
-    W, H = args.width, args.height
+    W, H = args.width or wl.get("width", 1920), args.height or wl.get("height", 1080)
     if H % 8:
         raise SystemExit("height must be a multiple of the 8-row stripe")
-    sc = build_scene_arrays(wl["scene"])
+    sc = build_scene_arrays(wl["scene"], args.obj)
+    from raytracer_amd import scenes as _scenes
     scene = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
     fkw = dict(FEATURE_BASE)
     fkw.update(wl["feat"])
     feat = api.Features(**fkw)
     cam = api.camera_from_trackball(W, H)
+    cams = [api.camera_from_trackball(W, H, rot_deg=(20.0, 20.0 + 360.0 * k / max(args.steps, 1), 0.0)) for k in range(args.steps)] \
+        if wl.get("orbit") else None
     region = api.Region(8, rank, world)
     flags = api.RT_RENDER_NO_CULL if args.no_cull else 0
     stream = torch.cuda.current_stream().cuda_stream
@@ -132,7 +142,8 @@ def main():
     def step(i=None):
         if i is not None:
             ev_r0[i].record()
-        scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region, flags=flags, stream=stream)
+        scene.render_device(cams[i] if (cams and i is not None) else cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region,
+                            flags=flags, stream=stream)
         if i is not None:
             ev_r1[i].record()
         plan.gather(frame, dist)
@@ -155,7 +166,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64, device=dev)
+    if cams:  # every frame of the sweep has its own ray count: recount them outside the timed region
+        tot = [0, 0, 0, 0]
+        for c in cams:
+            scene.render_device(c, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region, flags=flags, stream=stream)
+            st = scene.sync(stream)
+            for k, v in enumerate((st.primaryRays, st.shadowRays, st.secondaryRays, st.pixels)):
+                tot[k] += v / len(cams)
+        rays_rank = torch.tensor(tot, dtype=torch.float64, device=dev)
+    else:
+        rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(rays_rank)
@@ -197,7 +217,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "description": wl["desc"], "width": W, "height": H,
-                       "triangles": int(len(sc["prims"])), "rays_per_frame": int(rays_frame),
+                       "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
+                       "rays_per_frame": int(rays_frame),
                        "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (", RCCL all-gather" if world > 1 else ""),
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

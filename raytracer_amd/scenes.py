@@ -139,3 +139,130 @@ def merge(*scenes: dict) -> dict:
 
 def mesh_hash(scene: dict) -> str:
     return hashlib.sha256(np.ascontiguousarray(scene["prims"]).tobytes()).hexdigest()[:16]
+
+
+def _parse_mtl(path: str) -> dict:
+    mats, cur = {}, None
+    if not os.path.exists(path):
+        return mats
+    for line in open(path, errors="replace"):
+        t = line.split()
+        if not t or t[0].startswith("#"):
+            continue
+        if t[0] == "newmtl":
+            # tinyobj's material defaults: diffuse/specular 0, shininess 1, dissolve 1
+            cur = mats.setdefault(" ".join(t[1:]), dict(kd=[0, 0, 0], ks=[0, 0, 0], ns=1.0, d=1.0, tex=0.0))
+        elif cur is not None:
+            if t[0] == "Kd":
+                cur["kd"] = [float(x) for x in t[1:4]]
+            elif t[0] == "Ks":
+                cur["ks"] = [float(x) for x in t[1:4]]
+            elif t[0] == "Ns":
+                cur["ns"] = float(t[1])
+            elif t[0] == "d":
+                cur["d"] = float(t[1])
+            elif t[0] == "Tr":
+                cur["d"] = 1.0 - float(t[1])
+            elif t[0] == "map_Kd":
+                cur["tex"] = 1.0
+    return mats
+
+
+def load_obj(path: str, normalize: bool = True, light=(-1.0, 1.0, -1.0)) -> dict:
+    """loadMesh(file, normalize) (framework/src/mesh.cpp:52-149) for a Wavefront OBJ: one mesh per run of faces
+    with the same material inside a shape, quads split as tinyobjloader does, a vertex without a
+    normal gets its triangle's geometric normal, and - with `normalize` - the vertices (deduplicated per mesh
+    on position+normal+texcoord, as the loader's vertex cache does) are centred on their mean and scaled by
+    the largest distance to it (mesh.cpp:151-176).  The light defaults to the Dragon preset's (src/scene.cpp:88-93)."""
+    V, VN, VT = [], [], []
+    meshes = []  # (material name, [((vi, ti, ni) * 3)])
+    mtl = {}
+    cur_mat, cur_faces, shape_open = None, None, False
+
+    def flush():
+        nonlocal cur_faces
+        if cur_faces:
+            meshes.append((cur_mat, cur_faces))
+        cur_faces = []
+
+    def idx(tok, n):
+        i = int(tok)
+        return i - 1 if i > 0 else n + i
+
+    base = os.path.dirname(os.path.abspath(path))
+    cur_faces = []
+    for line in open(path, errors="replace"):
+        t = line.split()
+        if not t or t[0].startswith("#"):
+            continue
+        if t[0] == "v":
+            V.append([float(x) for x in t[1:4]])
+        elif t[0] == "vn":
+            VN.append([float(x) for x in t[1:4]])
+        elif t[0] == "vt":
+            VT.append([float(x) for x in t[1:3]])
+        elif t[0] == "mtllib":
+            mtl.update(_parse_mtl(os.path.join(base, " ".join(t[1:]))))
+        elif t[0] == "usemtl":
+            flush()
+            cur_mat = " ".join(t[1:])
+        elif t[0] in ("o", "g"):
+            flush()
+        elif t[0] == "f":
+            corners = []
+            for c in t[1:]:
+                p = c.split("/")
+                vi = idx(p[0], len(V))
+                ti = idx(p[1], len(VT)) if len(p) > 1 and p[1] else -1
+                ni = idx(p[2], len(VN)) if len(p) > 2 and p[2] else -1
+                corners.append((vi, ti, ni))
+            if len(corners) == 4:
+                # tinyobjloader splits a quad along its shorter diagonal (tiny_obj_loader.h:1463-1524), in float32
+                q = np.asarray([V[c[0]] for c in corners], np.float32)
+                e02, e13 = q[2] - q[0], q[3] - q[1]
+                s02 = (e02[0] * e02[0] + e02[1] * e02[1]) + e02[2] * e02[2]
+                s13 = (e13[0] * e13[0] + e13[1] * e13[1]) + e13[2] * e13[2]
+                if s02 < s13:
+                    cur_faces += [(corners[0], corners[1], corners[2]), (corners[0], corners[2], corners[3])]
+                else:
+                    cur_faces += [(corners[0], corners[1], corners[3]), (corners[1], corners[2], corners[3])]
+            else:  # triangles; larger polygons as a fan (tinyobjloader clips ears: only convex polygons agree)
+                for k in range(1, len(corners) - 1):
+                    cur_faces.append((corners[0], corners[k], corners[k + 1]))
+    flush()
+    if not meshes:
+        raise ValueError(f"{path}: no faces")
+    V = np.asarray(V, np.float32)
+    VN = np.asarray(VN, np.float32).reshape(-1, 3)
+    VT = np.asarray(VT, np.float32).reshape(-1, 2)
+    out_pos, out_nrm, out_uv, out_id, materials, dedup = [], [], [], [], [], []
+    for m, (name, faces) in enumerate(meshes):
+        f = np.asarray(faces, np.int64)  # (T, 3, 3)
+        pos = V[f[:, :, 0]]
+        geo = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]).astype(np.float32)
+        geo = (geo * (np.float32(1) / np.sqrt((geo[:, 0] * geo[:, 0] + geo[:, 1] * geo[:, 1]) + geo[:, 2] * geo[:, 2], dtype=np.float32))[:, None]).astype(np.float32)
+        nrm = np.repeat(geo[:, None, :], 3, axis=1)
+        has_n = f[:, :, 2] >= 0
+        if len(VN) and has_n.any():
+            nrm[has_n] = VN[f[:, :, 2][has_n]]
+        uv = np.zeros((len(f), 3, 2), np.float32)
+        has_t = f[:, :, 1] >= 0
+        if len(VT) and has_t.any():
+            uv[has_t] = VT[f[:, :, 1][has_t]]
+        out_pos.append(pos), out_nrm.append(nrm), out_uv.append(uv), out_id.append(np.full(len(f), m, np.uint32))
+        # the loader's vertex cache: first occurrence order of distinct (position, normal, texcoord)
+        key = np.concatenate([pos.reshape(-1, 3), nrm.reshape(-1, 3), uv.reshape(-1, 2)], axis=1).view(np.uint32)
+        _, first = np.unique(key, axis=0, return_index=True)
+        dedup.append(pos.reshape(-1, 3)[np.sort(first)])
+        mm = mtl.get(name)
+        materials.append([1, 1, 1, 0, 0, 0, 1.0, 1.0, 0.0] if mm is None else [*mm["kd"], *mm["ks"], mm["ns"], mm["d"], mm["tex"]])
+    pos = np.concatenate(out_pos)
+    if normalize:
+        allv = np.concatenate(dedup).astype(np.float32)
+        center = np.cumsum(allv, axis=0, dtype=np.float32)[-1] / np.float32(len(allv))
+        d = allv - center
+        maxd = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32).max()
+        pos = ((pos - center) / np.float32(maxd)).astype(np.float32)
+    prims = pack_prims(np.concatenate(out_id), pos, np.concatenate(out_nrm), np.concatenate(out_uv))
+    return dict(prims=prims, materials=np.asarray(materials, np.float32), lights=point_light(light)[None, :],
+                spheres=np.zeros((0, 12), np.float32))

@@ -341,3 +341,54 @@ def test_headline_config_at_full_size():
         assert abs(a - b) <= max(1, 1e-4 * b), (got, want)
     again = g.render_image(cg, fg, W, H, start_depth=2)
     assert np.array_equal(again["rgb"].view(np.uint32), rg["rgb"].view(np.uint32))
+
+
+def test_cpp_host_interface_renders_the_same_frame(tmp_path):
+    """raytracer_amd/host (BVH / Trackball / Screen / renderImage in the reference's shapes) against the Python
+    route to the same C ABI and against the oracle, on the example program's procedural scene."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "host")
+    exe = os.path.join(host, "example_render")
+    if not os.path.exists(exe):
+        pytest.fail("raytracer_amd/host/example_render is not built (python __graft_entry__.py build)")
+    W, H = 256, 192
+    out = tmp_path / "frame.rgbf32"
+    log = subprocess.run([exe, str(out), str(W), str(H), "2", "3"], check=True, capture_output=True, text=True, timeout=120).stdout
+    print(log)
+    got = np.fromfile(out, np.float32).reshape(H, W, 3)
+
+    def quad(a, b, c, d, n):
+        v = np.array([a, b, c, d], np.float32)
+        return v[[0, 1, 2, 0, 2, 3]].reshape(2, 3, 3), np.tile(np.array(n, np.float32), (2, 3, 1))
+
+    p0, n0 = quad((-1, -0.5, -1), (-1, -0.5, 1), (1, -0.5, 1), (1, -0.5, -1), (0, 1, 0))
+    p1, n1 = quad((-1, -0.5, -1), (1, -0.5, -1), (1, 1, -1), (-1, 1, -1), (0, 0, 1))
+    apex = np.array((0.1, 0.45, 0.05), np.float32)
+    base = np.array([(-0.3, -0.5, -0.3), (0.5, -0.5, -0.3), (0.5, -0.5, 0.5), (-0.3, -0.5, 0.5)], np.float32)
+    p2, n2 = [], []
+    for k in range(4):
+        a, b = base[(k + 1) % 4], base[k]
+        e1, e2 = b - a, apex - a
+        n = np.array([e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]], np.float32)
+        n = n / np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2], dtype=np.float32)
+        p2.append([a, b, apex]), n2.append([n, n, n])
+    pos = np.concatenate([p0, p1, np.array(p2, np.float32)])
+    nrm = np.concatenate([n0, n1, np.array(n2, np.float32)])
+    ids = np.array([0, 0, 1, 1, 2, 2, 2, 2], np.uint32)
+    prims = scenes.pack_prims(ids, pos, nrm, np.zeros((8, 3, 2), np.float32))
+    mats = np.array([[0.7, 0.7, 0.65, 0.1, 0.1, 0.1, 20, 1, 0], [0.8, 0.2, 0.2, 0, 0, 0, 1, 1, 0], [0.1, 0.1, 0.3, 0.8, 0.8, 0.8, 60, 1, 0]], np.float32)
+    lights = scenes.point_light((0.4, 1.2, 1.5))[None, :]
+    kw = dict(enableGlossyReflection=1, numGlossySamples=3, enableBloomEffect=1)
+    fg, fo = both_features(**kw)
+    cg, co = both_cameras(W, H)
+    g = api.Scene.from_triangles(prims, mats, lights, np.zeros((0, 12), np.float32))
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    assert np.array_equal(got.view(np.uint32), rg["rgb"].view(np.uint32)), "C++ host route and Python route differ"
+    o = O.OracleScene(prims, mats, lights)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    want = O.bloom(ro["rgb"], 15, 0.5, 0.8)
+    assert (rmse(got, want) <= RMSE_TOL).all()
+    st = rg["stats"]
+    assert f"rays primary {st.primaryRays} shadow {st.shadowRays} secondary {st.secondaryRays}" in log
+    assert "probe hit 1 t 1.5 normal 0 1 0" in log
