@@ -156,7 +156,7 @@ private:
 // without the window (the aspect ratio is given instead); angles in radians as in the reference's constructor.
 class Trackball {
 public:
-    Trackball(float aspectRatio, float fovy, vec3 lookAt = {}, float distance = 3.0f, float rotationX = 0.0f, float rotationY = 0.0f);
+    Trackball(float aspectRatio, float fovy, vec3 lookAt = {}, float distanceFromLookAt = 4.0f, float rotationX = 0.0f, float rotationY = 0.0f);
     void setCamera(vec3 lookAt, vec3 rotations, float distance);
     rt_camera deviceCamera() const;
 
