@@ -14,7 +14,10 @@
  *     listing), BVH build + traversal + hit record (src/bvh.cpp), the renderRay recursion
  *     driver, the glossy loop, the bloom driver, the camera and the Screen index (those
  *     reference files do not build in this image without GLU headers).  They are restated
- *     line by line with file:line citations in oracle.cpp.
+ *     line by line with file:line citations in oracle.cpp.  What does pin them end to end is the
+ *     number of rays the unmodified reference binary traces per frame (five configurations on
+ *     Cornell, monkey and teapot), which the restatement reproduces exactly
+ *     (tests/test_host_cpu.py), and the tree shapes the reference reports.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
