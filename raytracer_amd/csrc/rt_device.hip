@@ -53,10 +53,12 @@ struct rt_scene {
     void* d_hits = nullptr;       // hit records of the stage being traced
     size_t hitCap = 0;
     void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
+    uint32_t* d_longList = nullptr; // indices of the rays a one-ray-per-lane launch handed over (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
     uint32_t laneModeAbove = 131072; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
+    uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     std::vector<int> lightTypes;
 };
 
@@ -76,7 +78,7 @@ constexpr int kFrameFloats = 20; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
 constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
-constexpr uint32_t kMaxTraceLaunches = 2 * kMaxRounds + 1024; // work counters for the trace launches of one frame
+constexpr uint32_t kMaxTraceLaunches = 4 * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
@@ -178,6 +180,10 @@ struct RaySlabs {
     vec3 o, d, r;
     bool zx, zy, zz; // direction component == 0: the reference substitutes FLT_MAX / FLT_MIN
     bool fast;
+    // first-pass filter of pair_test: slab distance ~ fma(bound, r, nor), off from the exact quotient by less than eps
+    bool approx;
+    vec3 nor;  // -(o * r)
+    float eps;
 };
 __device__ __forceinline__ RaySlabs make_slabs(const SceneView& S, const vec3 o, const vec3 d)
 {
@@ -187,6 +193,14 @@ __device__ __forceinline__ RaySlabs make_slabs(const SceneView& S, const vec3 o,
     R.zx = d.x == 0.0f, R.zy = d.y == 0.0f, R.zz = d.z == 0.0f;
     R.fast = S.fastBounds != 0 && coord_in_fast_range(o.x) && coord_in_fast_range(o.y) && coord_in_fast_range(o.z)
         && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z);
+    R.approx = R.fast && !R.zx && !R.zy && !R.zz;
+    R.nor = make3(-(o.x * R.r.x), -(o.y * R.r.y), -(o.z * R.r.z));
+    // every box lies inside the root box: |bound| <= extent.  (|bound| + |o|) * |r| * 2^-22 * 1.25 bounds the distance
+    // between fma(bound, r, nor) and RN(RN(bound - o) / d); 2^-20 leaves a factor of three.
+    const float ex = fmaxf(fabsf(S.rootLo[0]), fabsf(S.rootHi[0])), ey = fmaxf(fabsf(S.rootLo[1]), fabsf(S.rootHi[1])),
+                ez = fmaxf(fabsf(S.rootLo[2]), fabsf(S.rootHi[2]));
+    R.eps = 9.5367431640625e-7f
+        * fmaxf((fabsf(o.x) + ex) * fabsf(R.r.x), fmaxf((fabsf(o.y) + ey) * fabsf(R.r.y), (fabsf(o.z) + ez) * fabsf(R.r.z)));
     return R;
 }
 // same decision sequence as box_test on precomputed slab distances
@@ -219,6 +233,37 @@ __device__ __forceinline__ bool box_test_any(const float lox, const float loy, c
     const bool h = box_test(lox, loy, loz, hix, hiy, hiz, R.o, R.d, tmax, t, outside);
     tOut = t;
     return h;
+}
+
+// The two sibling boxes of one NodePair (a, b = first record; c, e = second).  Same results as two box_test_any
+// calls against tmax = FLT_MAX.  The decisions (hit, origin inside, which child is nearer) are first taken on
+// cheap approximate slab distances; they are final when every comparison they rest on is decided by more than
+// the approximation's error bound, which is the case for all but grazing boxes.  Otherwise the exact slab
+// distances are computed.  tl / tr are only ever compared again (culling), with the same bound as margin.
+__device__ __forceinline__ void pair_test(const float4 a, const float4 b, const float4 c, const float4 e, const RaySlabs& R, bool& hl, bool& hr,
+                                          float& tl, float& tr, bool& outL, bool& outR)
+{
+    if (R.approx) {
+        const float uLx = fmaf(a.w, R.r.x, R.nor.x), uLy = fmaf(b.x, R.r.y, R.nor.y), uLz = fmaf(b.y, R.r.z, R.nor.z);
+        const float lLx = fmaf(a.x, R.r.x, R.nor.x), lLy = fmaf(a.y, R.r.y, R.nor.y), lLz = fmaf(a.z, R.r.z, R.nor.z);
+        const float uRx = fmaf(c.w, R.r.x, R.nor.x), uRy = fmaf(e.x, R.r.y, R.nor.y), uRz = fmaf(e.y, R.r.z, R.nor.z);
+        const float lRx = fmaf(c.x, R.r.x, R.nor.x), lRy = fmaf(c.y, R.r.y, R.nor.y), lRz = fmaf(c.z, R.r.z, R.nor.z);
+        const float inL = fmaxf(fmaxf(fminf(uLx, lLx), fminf(uLy, lLy)), fminf(uLz, lLz));
+        const float exL = fminf(fminf(fmaxf(uLx, lLx), fmaxf(uLy, lLy)), fmaxf(uLz, lLz));
+        const float inR = fmaxf(fmaxf(fminf(uRx, lRx), fminf(uRy, lRy)), fminf(uRz, lRz));
+        const float exR = fminf(fminf(fmaxf(uRx, lRx), fmaxf(uRy, lRy)), fmaxf(uRz, lRz));
+        const float E = R.eps, E2 = E + E;
+        outL = !(0.0f > inL), outR = !(0.0f > inR);
+        hl = outL ? !(inL > exL) : (exL > 0.0f);
+        hr = outR ? !(inR > exR) : (exR > 0.0f);
+        tl = outL ? inL : exL; // a box holding the origin reports its exit distance
+        tr = outR ? inR : exR;
+        const bool unsure = fabsf(inL) <= E || fabsf(exL) <= E || fabsf(inL - exL) <= E2 || fabsf(inR) <= E || fabsf(exR) <= E
+            || fabsf(inR - exR) <= E2 || (hl && hr && fabsf(tl - tr) <= E2);
+        if (!unsure) return;
+    }
+    hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, R, FLT_MAX, tl, outL);
+    hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, R, FLT_MAX, tr, outR);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,15 +430,13 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
                 const float4 a = q[0], b = q[1], c = q[2], e = q[3];
                 if (COUNT) tc.nodePairs++;
                 float tl, trr;
-                bool outL, outR;
-                bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, R, FLT_MAX, tl, outL);
-                bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, R, FLT_MAX, trr, outR);
+                bool outL, outR, hl, hr;
+                pair_test(a, b, c, e, R, hl, hr, tl, trr, outL, outR);
                 const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
-                // the reference compares the distances its box test REPORTED; a missed box leaves FLT_MAX
-                const bool leftNear = (hl ? tl : FLT_MAX) < (hr ? trr : FLT_MAX); // equal: right first (src/bvh.cpp:301-310)
-                if (CULL) {
-                    hl = hl && !(outL && tl > t);
-                    hr = hr && !(outR && trr > t);
+                const bool leftNear = tl < trr; // only used when both boxes are hit; equal: right first (src/bvh.cpp:301-310)
+                if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
+                    hl = hl && !(outL && tl - R.eps > t);
+                    hr = hr && !(outR && trr - R.eps > t);
                 }
                 if (hl && hr) {
                     const uint32_t nearRef = leftNear ? ref0 : ref1, farRef = leftNear ? ref1 : ref0;
@@ -1307,6 +1350,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.fastBounds = flat.fastBounds ? 1u : 0u;
     s->treeDepth = flat.maxDepth;
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) s->groupLanes = (uint32_t)atoi(e);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
@@ -1339,6 +1383,7 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_pathRays[1]);
     (void)hipFree(s->d_hits);
     (void)hipFree(s->d_shadowRays);
+    (void)hipFree(s->d_longList);
     delete s;
 }
 
@@ -1494,9 +1539,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         if (hitsWanted < scene->leafCap) hitsWanted = scene->leafCap;
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
         if (scene->hitCap < hitsWanted) {
-            (void)hipFree(scene->d_hits);
-            scene->d_hits = nullptr, scene->hitCap = 0;
+            (void)hipFree(scene->d_hits), (void)hipFree(scene->d_longList);
+            scene->d_hits = nullptr, scene->d_longList = nullptr, scene->hitCap = 0;
             RT_HIP(hipMalloc(&scene->d_hits, hitsWanted * sizeof(HitRec)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_longList), hitsWanted * sizeof(uint32_t)));
             scene->hitCap = hitsWanted;
         }
     }
@@ -1518,7 +1564,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
         chain *= nRays;
     }
-    if (chain > kMaxRounds - 1 || 2 * nChunks + 32 > kMaxTraceLaunches - 2 * kMaxRounds) {
+    if (chain > kMaxRounds - 1 || 4 * nChunks + 32 > kMaxTraceLaunches - 4 * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
                       (unsigned long long)chain, kMaxRounds - 1, nChunks);
@@ -1582,22 +1628,32 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         else RT_TRACE_CASE(false, true);
 #undef RT_TRACE_CASE
     };
-    // One stage of closest-hit queries.  Many rays: one ray per lane (throughput).  Few rays: several lanes per
-    // ray, which shortens the stage's slowest ray.  The ray count is only known on the device, so both variants
-    // are launched and the one whose range does not hold the count returns at once.
+    // One stage of closest-hit queries.  Many rays: one ray per lane (throughput), and the rays still unfinished
+    // after `stepBudget` steps start again with several lanes per ray, so that the stage does not wait for its few
+    // longest rays at one-lane speed.  Few rays: several lanes per ray from the start.  The ray count is only
+    // known on the device, so every variant is launched and those whose range does not hold the count return at once.
     const bool groupOk = features->enableAccelStructure && scene->treeDepth <= 30 && scene->groupLanes > 1;
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
+        T.indirect = nullptr, T.stepBudget = 0, T.longList = scene->d_longList, T.longCount = nullptr;
         T.runLo = 0, T.runHi = 0xffffffffu;
         if (!groupOk) {
             launch_one(1);
             return;
         }
+        uint32_t* longCount = scene->d_roundCounts + nextFetch++;
         T.runLo = scene->laneModeAbove;
+        T.stepBudget = count ? 0u : scene->stepBudget, T.longCount = longCount;
         launch_one(1);
-        T.runLo = 0, T.runHi = scene->laneModeAbove;
+        T.runLo = 0, T.runHi = scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
         launch_one(scene->groupLanes);
+        if (!count && scene->stepBudget) { // the handed-over rays (none unless the first launch ran)
+            T.runLo = 0, T.runHi = 0xffffffffu;
+            T.indirect = scene->d_longList;
+            T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
+            launch_one(scene->groupLanes);
+        }
     };
 
     P.activeIn = nullptr, P.activeInCount = nullptr;

@@ -173,6 +173,10 @@ struct TraceParams {
     uint32_t countSub, countMaxItems, countMul;
     uint32_t rayStride;       // bytes between ray records
     uint32_t runLo, runHi;    // the launch does nothing unless runLo <= number of rays < runHi (several variants share one ray list)
+    const uint32_t* indirect; // ray / hit index of item i (null: i itself)
+    uint32_t stepBudget;      // one-ray-per-lane launches: a ray still unfinished after this many steps is handed over (0: never)
+    uint32_t* longList;       // ... by appending its index here; a launch with several lanes per ray then traces it from the root
+    uint32_t* longCount;
     uint32_t* fetch;          // zeroed work counter of this launch
     unsigned long long* stats;
     uint32_t useBvh;
@@ -225,14 +229,13 @@ __device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uin
         const float4 a = q[0], b = q[1], c = q[2], e = q[3];
         if (COUNT) tc.nodePairs++;
         float tl, trr;
-        bool outL, outR;
-        bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, T.R, FLT_MAX, tl, outL);
-        bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, T.R, FLT_MAX, trr, outR);
+        bool outL, outR, hl, hr;
+        pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
         const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
         const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
-        if (CULL) {
-            hl = hl && !(outL && tl > T.t);
-            hr = hr && !(outR && trr > T.t);
+        if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
+            hl = hl && !(outL && tl - T.R.eps > T.t);
+            hr = hr && !(outR && trr - T.R.eps > T.t);
         }
         if (hl && hr) {
             if (T.sp < STACK) stack[T.sp * kBlock] = leftNear ? ref1 : ref0;
@@ -264,7 +267,8 @@ __device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uin
 __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
 {
     T.R.o = T.R.d = T.R.r = splat(0.0f);
-    T.R.zx = T.R.zy = T.R.zz = T.R.fast = false;
+    T.R.zx = T.R.zy = T.R.zz = T.R.fast = T.R.approx = false;
+    T.R.nor = splat(0.0f), T.R.eps = 0.0f;
     T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.sp = 0;
 }
 
@@ -282,27 +286,38 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
     const uint32_t total = items * P.countMul;
     if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
-    bool has = false, exhausted = false;
-    uint32_t idx = 0;
+    // The first ray of every lane is fixed by the lane's position in the grid; only later rays are taken from the
+    // shared counter (atomics on one address serialise: a launch with few rays must not pay one per wave).
+    const uint32_t gridLanes = gridDim.x * kBlock;
+    bool has = false, exhausted = total <= gridLanes, first = true;
+    uint32_t idx = 0, steps = 0;
+    const uint32_t budget = COUNT ? 0u : P.stepBudget; // a counting pass walks every ray exactly once
     TraceLane T;
     trace_lane_clear(T);
+    if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has);
-        if (idle != 0ull && !exhausted) {
-            const int leader = __ffsll((long long)idle) - 1;
-            const uint32_t n = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(P.fetch, n);
-            base = __shfl(base, leader);
-            exhausted = base + n >= total;
-            if (!has) {
-                idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < total) {
-                    const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
-                    const float4 a = q[0], b = q[1];
-                    has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
-                    if (!has) P.hits[idx] = HitRec { T.t, T.tri };
-                }
+        if (idle != 0ull && (first || !exhausted)) {
+            uint32_t next;
+            if (first) {
+                next = blockIdx.x * kBlock + threadIdx.x;
+            } else {
+                const int leader = __ffsll((long long)idle) - 1;
+                const uint32_t n = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(P.fetch, n);
+                base = __shfl(base, leader) + gridLanes;
+                exhausted = base + n >= total;
+                next = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            }
+            first = false;
+            if (!has) idx = next;
+            if (!has && idx < total) {
+                const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
+                const float4 a = q[0], b = q[1];
+                has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
+                steps = 0;
+                if (!has) P.hits[idx] = HitRec { T.t, T.tri };
             }
         }
         if (__ballot(has) == 0ull) {
@@ -313,6 +328,15 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
         for (int it = 0; it < kStepsPerCheck; it++) {
             if (has && trace_step<CULL, COUNT, STACK>(S, T, stack, tc)) {
                 P.hits[idx] = HitRec { T.t, T.tri };
+                has = false;
+            }
+        }
+        if (budget != 0) { // the few long rays would hold the whole stage at one-lane speed: hand them over
+            steps += kStepsPerCheck;
+            const bool giveUp = has && steps > budget;
+            const uint32_t pos = wave_fetch(P.longCount, giveUp, lane);
+            if (giveUp) {
+                P.longList[pos] = idx;
                 has = false;
             }
         }
@@ -999,13 +1023,14 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
         const float4 a = p[0], b = p[1], c = p[2], e = p[3];
         if (COUNT) tc.nodePairs++;
         float tl, trr;
-        bool outL, outR;
-        const bool hl = box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, T.R, FLT_MAX, tl, outL);
-        const bool hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, T.R, FLT_MAX, trr, outR);
+        bool outL, outR, hl, hr;
+        pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
         const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
         // the child the reference visits first (src/bvh.cpp:301-310: nearer first, equal distances: right first)
         const bool leftFirst = hl && (!hr || tl < trr);
-        const float el = outL ? tl : 0.0f, er = outR ? trr : 0.0f; // a box holding the origin is never culled
+        // entry distances kept for culling: a box holding the origin is never culled; the others only beyond the error
+        // bound of pair_test's approximate distances
+        const float el = outL ? tl - T.R.eps : 0.0f, er = outR ? trr - T.R.eps : 0.0f;
         const bool keepL = hl && !(CULL && el > T.cullT), keepR = hr && !(CULL && er > T.cullT);
         const uint32_t keyFirst = 2u * key, keySecond = (hl && hr) ? 2u * key + 1u : 2u * key;
         if (leftFirst) {
@@ -1109,29 +1134,43 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
     const uint32_t total = items * P.countMul;
     if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
-    bool has = false, exhausted = false; // has: same on every lane of a group
+    // The first ray of every group is fixed by the group's position in the grid; later rays come from the shared counter.
+    const uint32_t gridGroups = gridDim.x * (kBlock / G);
+    const uint32_t myGroup = blockIdx.x * (kBlock / G) + threadIdx.x / G;
+    bool has = false, exhausted = total <= gridGroups, first = true; // has: same on every lane of a group
     uint32_t idx = 0;
     GroupLane T;
     T.R.o = T.R.d = T.R.r = splat(0.0f);
-    T.R.zx = T.R.zy = T.R.zz = T.R.fast = false;
+    T.R.zx = T.R.zy = T.R.zz = T.R.fast = T.R.approx = false;
+    T.R.nor = splat(0.0f), T.R.eps = 0.0f;
     T.bestT = T.cullT = 0.0f, T.bestKey = 0, T.bestTri = kNoHit, T.nq = T.lq = 0;
+    if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) / G >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has && j == 0);
-        if (idle != 0ull && !exhausted) {
-            const int first = __ffsll((long long)idle) - 1;
-            const uint32_t n = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(P.fetch, n);
-            base = __shfl(base, first);
-            exhausted = base + n >= total;
+        if (idle != 0ull && (first || !exhausted)) {
+            uint32_t next;
+            if (first) {
+                next = myGroup;
+            } else {
+                const int firstIdle = __ffsll((long long)idle) - 1;
+                const uint32_t n = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == firstIdle) base = atomicAdd(P.fetch, n);
+                base = __shfl(base, firstIdle) + gridGroups;
+                exhausted = base + n >= total;
+                next = base + (uint32_t)__popcll(idle & ((1ull << leaderLane) - 1ull));
+            }
+            first = false;
+            bool valid = false;
             if (!has) {
-                idx = base + (uint32_t)__popcll(idle & ((1ull << leaderLane) - 1ull));
-                if (idx < total) {
-                    const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
-                    const float4 a = r[0], b = r[1];
-                    has = group_begin<G>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
-                    if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
-                }
+                valid = next < total;
+                idx = (valid && P.indirect) ? P.indirect[next] : next;
+            }
+            if (valid) {
+                const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
+                const float4 a = r[0], b = r[1];
+                has = group_begin<G>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
+                if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
             }
         }
         if (__ballot(has) == 0ull) {

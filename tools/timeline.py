@@ -2,7 +2,7 @@ import csv, sys
 tag = sys.argv[1]
 rows = [r for r in csv.DictReader(open('gpurun_out/prof_%s/p_kernel_trace.csv' % tag))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "primary_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "camera_kernel" in r["Kernel_Name"] or "primary_kernel" in r["Kernel_Name"]]
 fr = rows[idx[-2]:idx[-1]]
 t0 = int(fr[0]["Start_Timestamp"])
 sel = range(len(fr)) if len(sys.argv) < 3 else [int(x) for x in sys.argv[2].split(",")]
