@@ -9,7 +9,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "lib", "librt_amd.so")  # RT_AMD_LIB: an experimental build
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)

@@ -337,18 +337,22 @@ __device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t fir
         const bool c3 = m > 3 && t3 >= 0.0f && t >= t3;
         if (!(c0 || c1 || c2 || c3)) continue;
         const uint32_t b = first + k;
-        // triangles out of range re-read the first record: no branch between the loads, no new cache line
-        const EdgeRec E0 = load_edges(S, b);
-        const EdgeRec E1 = load_edges(S, c1 ? b + 1 : b);
-        const EdgeRec E2 = load_edges(S, c2 ? b + 2 : b);
-        const EdgeRec E3 = load_edges(S, c3 ? b + 3 : b);
-        const bool i0 = point_in_triangle(E0, d * t0 + o), i1 = point_in_triangle(E1, d * t1 + o);
-        const bool i2 = point_in_triangle(E2, d * t2 + o), i3 = point_in_triangle(E3, d * t3 + o);
-        // equal distance accepted: the later candidate wins the tie
-        if (c0 && i0) t = t0, tri = b;
-        if (c1 && i1 && t >= t1) t = t1, tri = b + 1;
-        if (c2 && i2 && t >= t2) t = t2, tri = b + 2;
-        if (c3 && i3 && t >= t3) t = t3, tri = b + 3;
+        // two edge records in flight at a time (a triangle out of range re-reads the pair's first record: no branch
+        // between the loads, no new cache line); equal distance accepted: the later candidate wins the tie
+        if (c0 || c1) {
+            const EdgeRec E0 = load_edges(S, b);
+            const EdgeRec E1 = load_edges(S, c1 ? b + 1 : b);
+            const bool i0 = point_in_triangle(E0, d * t0 + o), i1 = point_in_triangle(E1, d * t1 + o);
+            if (c0 && i0) t = t0, tri = b;
+            if (c1 && i1 && t >= t1) t = t1, tri = b + 1;
+        }
+        if (c2 || c3) {
+            const EdgeRec E2 = load_edges(S, c2 ? b + 2 : b + 3);
+            const EdgeRec E3 = load_edges(S, c3 ? b + 3 : b + 2);
+            const bool i2 = point_in_triangle(E2, d * t2 + o), i3 = point_in_triangle(E3, d * t3 + o);
+            if (c2 && i2 && t >= t2) t = t2, tri = b + 2;
+            if (c3 && i3 && t >= t3) t = t3, tri = b + 3;
+        }
     }
 }
 
@@ -1612,7 +1616,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         T.fetch = scene->d_roundCounts + nextFetch++;
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
     do {                                                                                                                  \
-        if (groupLanes == 8)                                                                                              \
+        if (groupLanes == 4)                                                                                              \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
+        else if (groupLanes == 8)                                                                                         \
             hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
         else if (groupLanes == 16)                                                                                        \
             hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \

@@ -272,10 +272,13 @@ __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
     T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.sp = 0;
 }
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES
+#endif
 constexpr int kStepsPerCheck = 6; // traversal steps between two looks at the wave's idle lanes
 
 template <bool CULL, bool COUNT, int STACK>
-__global__ __launch_bounds__(kBlock) void trace_kernel(const TraceParams P)
+__global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const TraceParams P)
 {
     __shared__ uint32_t s_stack[STACK * kBlock];
     uint32_t* const stack = s_stack + threadIdx.x;
