@@ -178,7 +178,6 @@ __device__ __forceinline__ bool dir_in_fast_range(const float x)
 }
 struct RaySlabs {
     vec3 o, d, r;
-    bool zx, zy, zz; // direction component == 0: the reference substitutes FLT_MAX / FLT_MIN
     bool fast;
     // first-pass filter of pair_test: slab distance ~ fma(bound, r, nor), off from the exact quotient by less than eps
     bool approx;
@@ -190,10 +189,9 @@ __device__ __forceinline__ RaySlabs make_slabs(const SceneView& S, const vec3 o,
     RaySlabs R;
     R.o = o, R.d = d;
     R.r = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    R.zx = d.x == 0.0f, R.zy = d.y == 0.0f, R.zz = d.z == 0.0f;
     R.fast = S.fastBounds != 0 && coord_in_fast_range(o.x) && coord_in_fast_range(o.y) && coord_in_fast_range(o.z)
         && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z);
-    R.approx = R.fast && !R.zx && !R.zy && !R.zz;
+    R.approx = R.fast && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f;
     R.nor = make3(-(o.x * R.r.x), -(o.y * R.r.y), -(o.z * R.r.z));
     // every box lies inside the root box: |bound| <= extent.  (|bound| + |o|) * |r| * 2^-22 * 1.25 bounds the distance
     // between fma(bound, r, nor) and RN(RN(bound - o) / d); 2^-20 leaves a factor of three.
@@ -222,8 +220,9 @@ __device__ __forceinline__ bool box_test_fast(const float lox, const float loy, 
 {
     const float qUx = div_by(hix - R.o.x, R.d.x, R.r.x), qUy = div_by(hiy - R.o.y, R.d.y, R.r.y), qUz = div_by(hiz - R.o.z, R.d.z, R.r.z);
     const float qLx = div_by(lox - R.o.x, R.d.x, R.r.x), qLy = div_by(loy - R.o.y, R.d.y, R.r.y), qLz = div_by(loz - R.o.z, R.d.z, R.r.z);
-    return box_decide(R.zx ? FLT_MAX : qUx, R.zy ? FLT_MAX : qUy, R.zz ? FLT_MAX : qUz, R.zx ? kFltMin : qLx, R.zy ? kFltMin : qLy,
-                      R.zz ? kFltMin : qLz, tmax, tOut, outside);
+    const bool zx = R.d.x == 0.0f, zy = R.d.y == 0.0f, zz = R.d.z == 0.0f; // the reference substitutes FLT_MAX / FLT_MIN
+    return box_decide(zx ? FLT_MAX : qUx, zy ? FLT_MAX : qUy, zz ? FLT_MAX : qUz, zx ? kFltMin : qLx, zy ? kFltMin : qLy,
+                      zz ? kFltMin : qLz, tmax, tOut, outside);
 }
 __device__ __forceinline__ bool box_test_any(const float lox, const float loy, const float loz, const float hix, const float hiy,
                                              const float hiz, const RaySlabs& R, const float tmax, float& tOut, bool& outside)
@@ -1610,7 +1609,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     uint32_t* const rayCounts = scene->d_roundCounts + kMaxRounds;
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
-    const uint32_t traceGrid = (uint32_t)scene->numCUs * 8u;
+    const uint32_t traceGrid = (uint32_t)scene->numCUs * (getenv("RT_AMD_TRACE_BLOCKS") ? (uint32_t)atoi(getenv("RT_AMD_TRACE_BLOCKS")) : 8u);
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     auto launch_one = [&](uint32_t groupLanes) {
         T.fetch = scene->d_roundCounts + nextFetch++;

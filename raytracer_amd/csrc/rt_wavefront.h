@@ -186,7 +186,9 @@ struct TraceParams {
 struct TraceLane {
     RaySlabs R;
     float t;
-    uint32_t tri, cur;
+    uint32_t tri;
+    uint32_t cur;  // inner node (pair index), leaf reference, or kTraversalDone
+    uint32_t pend; // a leaf reached but not tested yet (0: none)
     int sp;
 };
 
@@ -200,6 +202,7 @@ __device__ __forceinline__ bool trace_begin(const SceneView& S, const bool useBv
     T.t = tmax;
     T.tri = kNoHit;
     T.sp = 0;
+    T.pend = 0;
     if (useBvh) {
         float tr;
         bool outside;
@@ -218,48 +221,85 @@ __device__ __forceinline__ bool trace_begin(const SceneView& S, const bool useBv
     return false;
 }
 
-// One node pair or one leaf.  Returns true when the query has ended.
-template <bool CULL, bool COUNT, int STACK>
-__device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
+// Next pending node from the lane's stack into T.cur (kTraversalDone when the stack is empty).
+template <bool CULL, int STACK>
+__device__ __forceinline__ void lane_pop(TraceLane& T, const uint32_t* const stack)
 {
-    bool pop = false;
-    const uint32_t cur = T.cur;
-    if (!(cur & kLeafBit)) {
-        const float4* q = reinterpret_cast<const float4*>(S.pairs + cur);
-        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
-        if (COUNT) tc.nodePairs++;
-        float tl, trr;
-        bool outL, outR, hl, hr;
-        pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
-        const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
-        const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
-        if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
-            hl = hl && !(outL && tl - T.R.eps > T.t);
-            hr = hr && !(outR && trr - T.R.eps > T.t);
-        }
-        if (hl && hr) {
-            if (T.sp < STACK) stack[T.sp * kBlock] = leftNear ? ref1 : ref0;
-            else tc.overflow++;
-            T.sp++;
-            T.cur = leftNear ? ref0 : ref1;
-        } else if (hl || hr) {
-            T.cur = hl ? ref0 : ref1;
-        } else {
-            pop = true;
-        }
-    } else {
-        const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
-        leaf_test_narrow<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
-        pop = true;
-    }
-    if (pop) {
+    for (;;) {
         if (T.sp == 0) {
-            for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
-                if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
-            return true;
+            T.cur = kTraversalDone;
+            return;
         }
         T.sp--;
-        T.cur = (T.sp < STACK) ? stack[T.sp * kBlock] : kLeafBit; // overflowed entries were dropped (counted)
+        if (T.sp >= STACK) continue; // overflowed entries were dropped (counted)
+        T.cur = stack[T.sp * kBlock];
+        // a box entered beyond the closest hit found since it was pushed holds nothing closer
+        if (!CULL || !(__uint_as_float(stack[(STACK + T.sp) * kBlock]) > T.t)) return;
+    }
+}
+
+// One inner node: both child boxes, nearer child next, the other pushed.
+template <bool CULL, bool COUNT, int STACK>
+__device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
+{
+    const float4* q = reinterpret_cast<const float4*>(S.pairs + T.cur);
+    const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+    if (COUNT) tc.nodePairs++;
+    float tl, trr;
+    bool outL, outR, hl, hr;
+    pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
+    const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
+    const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
+    if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
+        hl = hl && !(outL && tl - T.R.eps > T.t);
+        hr = hr && !(outR && trr - T.R.eps > T.t);
+    }
+    if (hl && hr) {
+        if (T.sp < STACK) {
+            stack[T.sp * kBlock] = leftNear ? ref1 : ref0;
+            // the far child's entry distance, to be compared again when it is popped (0: never culled)
+            const bool farOut = leftNear ? outR : outL;
+            stack[(STACK + T.sp) * kBlock] = __float_as_uint(farOut ? (leftNear ? trr : tl) - T.R.eps : 0.0f);
+        } else {
+            tc.overflow++;
+        }
+        T.sp++;
+        T.cur = leftNear ? ref0 : ref1;
+    } else if (hl || hr) {
+        T.cur = hl ? ref0 : ref1;
+    } else {
+        lane_pop<CULL, STACK>(T, stack);
+    }
+}
+
+// One step of every lane of a wave (`has`: the lane has a query in flight).  Lanes at an inner node test it.
+// A lane that reaches a leaf parks it and goes on to its next node; parked leaves are tested together, when
+// kLeafBatch lanes have one or a lane cannot go on without testing its own (it reached a second leaf, or its
+// stack is empty) - a wave then runs the long triangle code for many lanes at once instead of for the one or
+// two that happen to be at a leaf.  Leaves are still tested in the order they are reached, so equal-distance
+// ties fall as in the reference.  Returns true for lanes whose query has ended.
+constexpr int kLeafBatch = 20;
+template <bool CULL, bool COUNT, int STACK>
+__device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
+{
+    if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) lane_node_step<CULL, COUNT, STACK>(S, T, stack, tc);
+    if (has && T.cur != kTraversalDone && (T.cur & kLeafBit) && T.pend == 0) {
+        T.pend = T.cur | kLeafBit;
+        lane_pop<CULL, STACK>(T, stack);
+    }
+    const bool parked = has && T.pend != 0;
+    const bool stuck = parked && (T.cur == kTraversalDone || (T.cur & kLeafBit));
+    if (__ballot(stuck) != 0ull || __popcll(__ballot(parked)) >= kLeafBatch) {
+        if (parked) {
+            const uint32_t first = T.pend & kRefOffsetMask, cnt = (T.pend >> kRefCountShift) & kMaxLeafCount;
+            leaf_test_narrow<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
+            T.pend = 0;
+        }
+    }
+    if (has && T.cur == kTraversalDone && T.pend == 0) {
+        for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+            if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
+        return true;
     }
     return false;
 }
@@ -267,20 +307,22 @@ __device__ __forceinline__ bool trace_step(const SceneView& S, TraceLane& T, uin
 __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
 {
     T.R.o = T.R.d = T.R.r = splat(0.0f);
-    T.R.zx = T.R.zy = T.R.zz = T.R.fast = T.R.approx = false;
+    T.R.fast = T.R.approx = false;
     T.R.nor = splat(0.0f), T.R.eps = 0.0f;
-    T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.sp = 0;
+    T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.pend = 0, T.sp = 0;
 }
 
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES
 #endif
 constexpr int kStepsPerCheck = 6; // traversal steps between two looks at the wave's idle lanes
+constexpr uint32_t kLaneChunk = 64;  // rays a wave takes from the shared counter at a time
+constexpr uint32_t kGroupChunk = 32; // the same for a wave whose lanes share rays
 
 template <bool CULL, bool COUNT, int STACK>
 __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const TraceParams P)
 {
-    __shared__ uint32_t s_stack[STACK * kBlock];
+    __shared__ uint32_t s_stack[2 * STACK * kBlock]; // per lane: STACK node references, then their entry distances
     uint32_t* const stack = s_stack + threadIdx.x;
     const SceneView& S = P.S;
     const int lane = threadIdx.x & 63;
@@ -289,29 +331,34 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
     const uint32_t total = items * P.countMul;
     if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
-    // The first ray of every lane is fixed by the lane's position in the grid; only later rays are taken from the
-    // shared counter (atomics on one address serialise: a launch with few rays must not pay one per wave).
+    // Work distribution.  Atomics on one address serialise (about 10 ns each on this chip), so a wave must not pay one
+    // per refill: the first ray of every lane is fixed by the lane's position in the grid, and later rays are
+    // taken from the shared counter in chunks of kLaneChunk that the wave then hands to its idle lanes by itself.
     const uint32_t gridLanes = gridDim.x * kBlock;
     bool has = false, exhausted = total <= gridLanes, first = true;
-    uint32_t idx = 0, steps = 0;
+    uint32_t idx = 0, steps = 0, chunkNext = 0, chunkEnd = 0; // [chunkNext, chunkEnd): rays this wave holds (wave-uniform)
     const uint32_t budget = COUNT ? 0u : P.stepBudget; // a counting pass walks every ray exactly once
     TraceLane T;
     trace_lane_clear(T);
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has);
-        if (idle != 0ull && (first || !exhausted)) {
-            uint32_t next;
+        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd)) {
+            uint32_t next = 0xffffffffu;
             if (first) {
                 next = blockIdx.x * kBlock + threadIdx.x;
             } else {
-                const int leader = __ffsll((long long)idle) - 1;
-                const uint32_t n = (uint32_t)__popcll(idle);
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(P.fetch, n);
-                base = __shfl(base, leader) + gridLanes;
-                exhausted = base + n >= total;
-                next = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (chunkNext == chunkEnd) { // !exhausted here
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.fetch, kLaneChunk);
+                    base = __shfl(base, 0) + gridLanes;
+                    exhausted = base + kLaneChunk >= total;
+                    chunkNext = min(base, total), chunkEnd = min(base + kLaneChunk, total);
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t avail = chunkEnd - chunkNext, n = (uint32_t)__popcll(idle);
+                if (rank < avail) next = chunkNext + rank;
+                chunkNext += min(n, avail);
             }
             first = false;
             if (!has) idx = next;
@@ -324,12 +371,12 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
             }
         }
         if (__ballot(has) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && chunkNext == chunkEnd) break;
             continue;
         }
 #pragma unroll 1
         for (int it = 0; it < kStepsPerCheck; it++) {
-            if (has && trace_step<CULL, COUNT, STACK>(S, T, stack, tc)) {
+            if (trace_wave_step<CULL, COUNT, STACK>(S, has, T, stack, tc)) {
                 P.hits[idx] = HitRec { T.t, T.tri };
                 has = false;
             }
@@ -858,86 +905,6 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
     flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
 }
 
-// The rest of every active pixel's sequential part in ONE launch: a lane takes an active state, traces
-// its ray, advances the recursion to the next ray, traces that, ... until the pixel ends, then takes the
-// next state.  Pixels no longer wait for the slowest ray of a round, so the frame's critical path is the
-// longest single pixel instead of the sum of every round's slowest ray.  Tracing lanes and lanes whose ray
-// has ended share a wave: the recursion code runs when enough lanes wait for it (a quarter of the wave's
-// busy lanes), or when nothing is left to trace.
-template <bool CULL, bool COUNT, int STACK>
-__global__ __launch_bounds__(kBlock) void chain_kernel(const WaveParams P, uint32_t* const fetch)
-{
-    __shared__ uint32_t s_stack[STACK * kBlock];
-    uint32_t* const stack = s_stack + threadIdx.x;
-    const SceneView& S = P.S;
-    const int lane = threadIdx.x & 63;
-    const bool useBvh = P.F.enableAccelStructure != 0;
-    const uint32_t total = *P.activeInCount;
-    uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
-    TraceCounters tc { 0, 0, 0 };
-    enum { IDLE = 0, TRACING = 1, TRACED = 2 };
-    int phase = IDLE;
-    bool exhausted = false;
-    uint32_t slot = 0;
-    TraceLane T;
-    trace_lane_clear(T);
-    for (;;) {
-        const unsigned long long idle = __ballot(phase == IDLE);
-        if (idle != 0ull && !exhausted) {
-            const int leader = __ffsll((long long)idle) - 1;
-            const uint32_t n = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(fetch, n);
-            base = __shfl(base, leader);
-            exhausted = base + n >= total;
-            if (phase == IDLE) {
-                const uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < total) {
-                    slot = P.activeIn[idx];
-                    const float4* q = reinterpret_cast<const float4*>(P.pathRays + idx);
-                    const float4 a = q[0], b = q[1];
-                    phase = trace_begin<COUNT>(S, useBvh, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc) ? TRACING : TRACED;
-                }
-            }
-        }
-        const unsigned long long tracing = __ballot(phase == TRACING), traced = __ballot(phase == TRACED);
-        if ((tracing | traced) == 0ull) {
-            if (exhausted) break;
-            continue;
-        }
-        const int nTraced = __popcll(traced), nBusy = __popcll(tracing | traced);
-        if (tracing != 0ull && 4 * nTraced < nBusy) {
-#pragma unroll 1
-            for (int it = 0; it < kStepsPerCheck; it++)
-                if (phase == TRACING && trace_step<CULL, COUNT, STACK>(S, T, stack, tc)) phase = TRACED;
-        } else {
-            PathLane L;
-            L.state = PS_DONE;
-            float* frames = nullptr;
-            float* st = nullptr;
-            if (phase == TRACED) {
-                st = P.states + (size_t)slot * kStateDwords;
-                load_header(st, L);
-                frames = st + 16;
-                L.tt = T.t;
-                L.ttri = T.tri;
-                L.state = PS_HIT;
-            }
-            auto alloc = [&](const bool) {}; // active states own their frame storage
-            advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
-            if (phase == TRACED) {
-                if (L.state == PS_TRACE) {
-                    store_header(st, L);
-                    phase = trace_begin<COUNT>(S, useBvh, T, L.to, L.td, FLT_MAX, tc) ? TRACING : TRACED;
-                } else {
-                    phase = IDLE;
-                }
-            }
-        }
-    }
-    flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Group traversal: G lanes share one ray.
 //
@@ -1137,31 +1104,36 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
     const uint32_t total = items * P.countMul;
     if (total < P.runLo || total >= P.runHi) return;
     TraceCounters tc { 0, 0, 0 };
-    // The first ray of every group is fixed by the group's position in the grid; later rays come from the shared counter.
+    // The first ray of every group is fixed by the group's position in the grid; later rays come from the shared
+    // counter in chunks of kGroupChunk per wave (see trace_kernel).
     const uint32_t gridGroups = gridDim.x * (kBlock / G);
     const uint32_t myGroup = blockIdx.x * (kBlock / G) + threadIdx.x / G;
     bool has = false, exhausted = total <= gridGroups, first = true; // has: same on every lane of a group
-    uint32_t idx = 0;
+    uint32_t idx = 0, chunkNext = 0, chunkEnd = 0;
     GroupLane T;
     T.R.o = T.R.d = T.R.r = splat(0.0f);
-    T.R.zx = T.R.zy = T.R.zz = T.R.fast = T.R.approx = false;
+    T.R.fast = T.R.approx = false;
     T.R.nor = splat(0.0f), T.R.eps = 0.0f;
     T.bestT = T.cullT = 0.0f, T.bestKey = 0, T.bestTri = kNoHit, T.nq = T.lq = 0;
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) / G >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has && j == 0);
-        if (idle != 0ull && (first || !exhausted)) {
-            uint32_t next;
+        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd)) {
+            uint32_t next = 0xffffffffu;
             if (first) {
                 next = myGroup;
             } else {
-                const int firstIdle = __ffsll((long long)idle) - 1;
-                const uint32_t n = (uint32_t)__popcll(idle);
-                uint32_t base = 0;
-                if (lane == firstIdle) base = atomicAdd(P.fetch, n);
-                base = __shfl(base, firstIdle) + gridGroups;
-                exhausted = base + n >= total;
-                next = base + (uint32_t)__popcll(idle & ((1ull << leaderLane) - 1ull));
+                if (chunkNext == chunkEnd) { // !exhausted here
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.fetch, kGroupChunk);
+                    base = __shfl(base, 0) + gridGroups;
+                    exhausted = base + kGroupChunk >= total;
+                    chunkNext = min(base, total), chunkEnd = min(base + kGroupChunk, total);
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << leaderLane) - 1ull));
+                const uint32_t avail = chunkEnd - chunkNext, n = (uint32_t)__popcll(idle);
+                if (rank < avail) next = chunkNext + rank;
+                chunkNext += min(n, avail);
             }
             first = false;
             bool valid = false;
@@ -1177,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
             }
         }
         if (__ballot(has) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && chunkNext == chunkEnd) break;
             continue;
         }
 #pragma unroll 1
