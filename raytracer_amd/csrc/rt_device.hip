@@ -1666,7 +1666,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     P.activeRayIn = nullptr, P.activeRayOut = scene->d_activeRay[0], P.rayCountOut = rayCounts;
     hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
     for (uint32_t r = 1; r <= rounds; r++) {
-        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), rayCounts + (r - 1), 0, P.rayCap, 1);
+        // the camera kernel emits exactly one ray per active state and counts them once
+        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1);
         P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
         P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
         P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;

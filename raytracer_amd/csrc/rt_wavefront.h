@@ -139,6 +139,25 @@ __device__ __forceinline__ uint32_t wave_fetch(uint32_t* counter, const bool nee
     return need ? base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) : 0xffffffffu;
 }
 
+// wave_fetch for a whole workgroup: one atomic per workgroup instead of one per wave (atomics on one address
+// serialise).  Every thread of the workgroup must call it; s_n (4 words) and s_base are the caller's LDS.
+__device__ __forceinline__ uint32_t block_fetch(uint32_t* counter, const bool need, const int lane, uint32_t* s_n, uint32_t* s_base)
+{
+    const unsigned long long mask = __ballot(need);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) s_n[wv] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        *s_base = n ? atomicAdd(counter, n) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = *s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    for (int k = 0; k < wv; k++) pos += s_n[k];
+    __syncthreads();
+    return need ? pos : 0xffffffffu;
+}
+
 __device__ __forceinline__ void flush_counters(unsigned long long* stats, const int lane, const uint32_t cPrimary, const uint32_t cShadow,
                                                const uint32_t cSecondary, const TraceCounters& tc, const uint32_t cPixels, const uint32_t cDrop)
 {
@@ -836,8 +855,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
-            s_base = n ? atomicAdd(P.activeOutCount, n) : 0u;
-            if (n) atomicAdd(P.rayCountOut, n);
+            s_base = n ? atomicAdd(P.activeOutCount, n) : 0u; // also the number of rays: the host reads round 0's from here
         }
         __syncthreads();
         uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -858,6 +876,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
 __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 {
+    __shared__ uint32_t s_n[4], s_base;
     const int lane = threadIdx.x & 63;
     const uint32_t total = *P.activeInCount;
     uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
@@ -887,9 +906,9 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
         advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
         const bool active = (L.state == PS_TRACE);
-        const uint32_t pos = wave_fetch(P.activeOutCount, active, lane);
+        const uint32_t pos = block_fetch(P.activeOutCount, active, lane, s_n, &s_base);
         const bool single = active && L.nRays <= 1;
-        const uint32_t rpos = wave_fetch(P.rayCountOut, single, lane); // a batch reserved its rays when it was emitted
+        const uint32_t rpos = block_fetch(P.rayCountOut, single, lane, s_n, &s_base); // a batch reserved its rays when it was emitted
         if (single) {
             L.nRays = 1;
             L.rayBase = rpos;
@@ -1174,6 +1193,7 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
 // Deferred rays at the recursion limit: a hit becomes a ShadeTask.
 __global__ __launch_bounds__(kBlock) void leaf_logic_kernel(const WaveParams P)
 {
+    __shared__ uint32_t s_n[4], s_base;
     const int lane = threadIdx.x & 63;
     const uint32_t total = min(P.qCount[1], P.leafCap);
     TraceCounters tc { 0, 0, 0 };
@@ -1201,7 +1221,16 @@ __global__ __launch_bounds__(kBlock) void leaf_logic_kernel(const WaveParams P)
                 want = true;
             }
         }
-        if (!queue_append(P.shadeQ, P.qCount + 0, P.shadeCap, want, st, lane)) cDrop++;
+        const uint32_t slot = block_fetch(P.qCount + 0, want, lane, s_n, &s_base);
+        if (want) {
+            if (slot < P.shadeCap) {
+                const float4* src = reinterpret_cast<const float4*>(&st);
+                float4* dst = reinterpret_cast<float4*>(P.shadeQ + slot);
+                dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+            } else {
+                cDrop++;
+            }
+        }
     }
     flush_counters(P.stats, lane, 0, 0, 0, tc, 0, cDrop);
 }
