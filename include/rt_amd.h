@@ -24,7 +24,7 @@ typedef enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID = 1,     /* bad argument (null pointer, size mismatch, index out of range) */
     RT_ERR_HIP = 2,         /* a HIP runtime call failed; message holds hipGetErrorString */
-    RT_ERR_UNSUPPORTED = 3, /* a feature flag this build does not implement on the GPU */
+    RT_ERR_UNSUPPORTED = 3, /* a feature flag this build does not implement on the GPU (enableTextureMapping) */
     RT_ERR_NOMEM = 4,
     RT_ERR_LIMIT = 5        /* a size beyond a documented limit (tree depth, leaf size, filter size) */
 } rt_status;
@@ -77,7 +77,11 @@ enum {
                                   (src/bvh.cpp:289-297), instead of skipping boxes beyond the closest hit */
     RT_RENDER_SERIAL = 4       /* flag: evaluate each pixel as one depth-first recursion and sum radiance in the
                                   reference's nested float order (src/recursive.cpp:25-83); the default pipeline
-                                  defers shadow rays and last-level rays and sums per pixel in fixed point */
+                                  defers shadow rays and last-level rays and sums per pixel in fixed point.
+                                  Implied by enableTransparency (pass-through rays, src/recursive.cpp:112-123,155-163,
+                                  and light through transparent occluders, src/light.cpp:107-136, whose walk - endless
+                                  in the reference when the shaded surface is met more than 1e-5 off - stops after
+                                  64 surfaces) */
 };
 
 typedef struct rt_bvh rt_bvh;     /* host-side BVH in the reference's node / primitive layout */

@@ -74,12 +74,13 @@ struct rt_scene {
 namespace {
 
 constexpr int kBlock = 256;     // 4 waves per workgroup
-constexpr int kFrameFloats = 20; // per recursion level saved state
+constexpr int kFrameFloats = 28; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
 constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
 constexpr uint32_t kMaxTraceLaunches = 4 * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
+constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is followed through (transparent shadows)
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
 enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
@@ -561,10 +562,11 @@ __device__ __forceinline__ Mat load_material(const SceneView& S, const uint32_t 
 // ---------------------------------------------------------------------------------------------
 // Shading models (src/shading.cpp:29-233); kd is the material colour (textures not carried)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ vec3 lambert(const vec3 lightDirection, const vec3 lightColor, const vec3 normal, const Mat& m)
+__device__ __forceinline__ vec3 lambert(const rt_features& F, const vec3 lightDirection, const vec3 lightColor, const vec3 normal, const Mat& m)
 {
     const vec3 l = normalize(lightDirection), n = normalize(normal);
-    const float dt = dot(l, n);
+    float dt = dot(l, n);
+    if (F.enableTransparency && m.transparency < 1.0f && dt < 0) dt = -dt; // lit from behind through the surface (src/shading.cpp:67-69)
     if (dt <= 0) return splat(0.0f);
     return m.kd * lightColor * dt;
 }
@@ -589,11 +591,12 @@ __device__ vec3 shade(const rt_features& F, const vec3 cameraDirection, const ve
 {
     if (!F.enableShading) return lightColor * m.kd;
     switch (F.shadingModel) {
-    case 0: return lambert(lightDirection, lightColor, normal, m);
+    case 0: return lambert(F, lightDirection, lightColor, normal, m);
     case 1: { // computePhongModel, src/shading.cpp:92-123
-        const vec3 diffuse = lambert(lightDirection, lightColor, normal, m);
+        const vec3 diffuse = lambert(F, lightDirection, lightColor, normal, m);
         const vec3 d = normalize(-lightDirection), n = normalize(normal);
-        const float dt = dot(-d, n);
+        float dt = dot(-d, n);
+        if (F.enableTransparency && m.transparency < 1.0f && dt < 0) dt = -dt; // src/shading.cpp:103-105
         if (dt <= 0) return diffuse;
         const vec3 v = normalize(cameraDirection);
         const vec3 r = normalize(d - 2.0f * dot(d, n) * n);
@@ -603,7 +606,7 @@ __device__ vec3 shade(const rt_features& F, const vec3 cameraDirection, const ve
         return diffuse + pw * m.ks * lightColor;
     }
     case 2: { // computeBlinnPhongModel, src/shading.cpp:140-169
-        const vec3 diffuse = lambert(lightDirection, lightColor, normal, m);
+        const vec3 diffuse = lambert(F, lightDirection, lightColor, normal, m);
         const vec3 d = normalize(lightDirection), n = normalize(normal);
         const float dt = dot(n, d);
         if (dt <= 0) return diffuse;
@@ -650,8 +653,8 @@ __device__ __forceinline__ void camera_ray(const rt_camera& cam, const float ndc
 // closest-hit queries - primary, shadow, reflection - through the single trace() call in the loop
 // body, so a wave keeps traversing together whatever mix of ray kinds its lanes hold.
 // ---------------------------------------------------------------------------------------------
-enum LaneState : int { ST_NEW = 0, ST_EXIT, ST_TRACE, ST_HIT_RAD, ST_HIT_SHD, ST_LIGHTS, ST_SPAWN, ST_GLOSSY_NEXT, ST_RETURN };
-enum ChildKind : int { CK_SPEC = 0, CK_GLOSSY = 1 };
+enum LaneState : int { ST_NEW = 0, ST_EXIT, ST_TRACE, ST_HIT_RAD, ST_HIT_SHD, ST_LIGHTS, ST_SPAWN, ST_GLOSSY_NEXT, ST_PASS, ST_RETURN };
+enum ChildKind : int { CK_SPEC = 0, CK_GLOSSY = 1, CK_PASS = 2 };
 
 template <bool CULL, bool COUNT, bool PERSISTENT>
 __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
@@ -685,6 +688,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
     // light loop
     uint32_t lightIdx = 0, lightSample = 0;
     vec3 areaAcc = splat(0.0f), lpos = splat(0.0f), lcol = splat(0.0f);
+    vec3 shIncoming = splat(0.0f), shPrev = splat(0.0f); // light through transparent occluders (src/light.cpp:107-136)
+    uint32_t shSegments = 0;
     vec3 ret = splat(0.0f);
     // counters
     uint32_t cPrimary = 0, cShadow = 0, cSecondary = 0, cPixels = 0;
@@ -807,6 +812,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                     td = normalize(ip - lpos);
                     tt = FLT_MAX;
                     traceIsShadow = true;
+                    shIncoming = shPrev = lcol;
+                    shSegments = 1;
                     cShadow++;
                     state = ST_TRACE;
                 } else {
@@ -818,7 +825,33 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
             }
             case ST_HIT_SHD: {
                 vec3 visible = lcol;
-                if (F.enableShadows) {
+                if (F.enableShadows && F.enableTransparency) {
+                    // visibilityOfLightSampleTransparency (src/light.cpp:107-136): walk from the light through every
+                    // surface on the way; each one tints and dims what gets past it; the light that reaches the LAST
+                    // surface met counts
+                    const vec3 ip = ro + rt * rd;
+                    const bool intersects = (ttri != kNoHit);
+                    const bool finalRayT = fabsf(tt - length(ip - to)) <= 1e-5f;
+                    if (intersects) {
+                        const bool sph = ttri >= kSphereBase;
+                        const Mat hm = load_material(S, sph ? ttri - kSphereBase : S.triAttr[ttri].meshID, sph);
+                        shPrev = shIncoming;
+                        shIncoming = shIncoming * hm.kd * (1.0f - hm.transparency);
+                        to = to + (tt + 1e-6f) * td;
+                    }
+                    // The reference's walk ends only when a surface is met within 1e-5 of the shading point or nothing
+                    // is hit; when the shaded surface itself is met a little further off, it oscillates around it for
+                    // ever.  A kernel must end: the walk stops after kMaxShadowSegments surfaces.
+                    if (intersects && !finalRayT && shSegments < kMaxShadowSegments) {
+                        shSegments++;
+                        td = normalize(ip - to);
+                        tt = FLT_MAX;
+                        cShadow++;
+                        state = ST_TRACE;
+                        break;
+                    }
+                    visible = shPrev;
+                } else if (F.enableShadows) {
                     const vec3 ip = ro + rt * rd;
                     const bool intersects = (ttri != kNoHit);
                     const bool expected = fabsf(tt - length(ip - lpos)) <= 5e-4f;
@@ -839,17 +872,27 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                 break;
             }
             case ST_SPAWN: {
-                // recursive components (src/recursive.cpp:62-80)
+                // recursive components (src/recursive.cpp:62-80): reflection first, then the pass-through ray
                 bool spawned = false;
-                if (depth < RT_MAX_RAY_DEPTH && F.enableReflections) {
+                float* fr = frames + (depth < RT_MAX_RAY_DEPTH ? depth : 0) * kFrameFloats; // a ray at the depth limit has no frame
+                if (depth < RT_MAX_RAY_DEPTH) fr[27] = 0.0f;
+                if (depth < RT_MAX_RAY_DEPTH && (F.enableReflections || F.enableTransparency)) {
                     const Mat m = load_material(S, hmesh, hsphere);
+                    if (F.enableTransparency && m.transparency != 1.f) {
+                        // generatePassthroughRay (src/recursive.cpp:112-123), kept until the reflection has returned
+                        vec3 porg = ro + rt * rd;
+                        porg = porg + 0.00001f * rd;
+                        fr[20] = porg.x, fr[21] = porg.y, fr[22] = porg.z;
+                        fr[23] = rd.x, fr[24] = rd.y, fr[25] = rd.z;
+                        fr[26] = m.transparency;
+                        fr[27] = 1.0f;
+                    }
                     const bool reflective = (m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f);
-                    if (reflective) {
+                    if (F.enableReflections && reflective) {
                         // generateReflectionRay (src/recursive.cpp:91-103)
                         vec3 rorg = ro + rt * rd;
                         const vec3 rdir = rd - 2.f * dot(rd, hn) * hn;
                         rorg = rorg + 0.00001f * rdir;
-                        float* fr = frames + depth * kFrameFloats;
                         fr[0] = Lo.x, fr[1] = Lo.y, fr[2] = Lo.z;
                         fr[3] = m.ks.x, fr[4] = m.ks.y, fr[5] = m.ks.z;
                         if (!F.enableGlossyReflection) { // renderRaySpecularComponent (src/recursive.cpp:135-143)
@@ -873,7 +916,21 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                         }
                     }
                 }
-                if (!spawned) {
+                if (!spawned) state = ST_PASS; // Lo = the hit's colour so far
+                break;
+            }
+            case ST_PASS: {
+                // renderRayTransparentComponent (src/recursive.cpp:155-163) of the hit at `depth`, whose colour so far is Lo
+                float* fr = frames + (depth < RT_MAX_RAY_DEPTH ? depth : 0) * kFrameFloats;
+                if (depth < RT_MAX_RAY_DEPTH && fr[27] != 0.0f) {
+                    fr[0] = Lo.x, fr[1] = Lo.y, fr[2] = Lo.z;
+                    fr[6] = __int_as_float(CK_PASS);
+                    to = make3(fr[20], fr[21], fr[22]), td = make3(fr[23], fr[24], fr[25]), tt = FLT_MAX;
+                    traceIsShadow = false;
+                    depth++;
+                    cSecondary++;
+                    state = ST_TRACE;
+                } else {
                     ret = Lo;
                     state = ST_RETURN;
                 }
@@ -908,8 +965,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                 }
                 if (!launched) { // hitColor += accumulatedColor / float(numSamples) (src/extra.cpp:507)
                     const vec3 acc = make3(fr[17], fr[18], fr[19]);
-                    ret = make3(fr[0], fr[1], fr[2]) + acc / float(F.numGlossySamples);
-                    state = ST_RETURN;
+                    Lo = make3(fr[0], fr[1], fr[2]) + acc / float(F.numGlossySamples);
+                    state = ST_PASS;
                 }
                 break;
             }
@@ -960,7 +1017,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                 const int kind = __float_as_int(fr[6]);
                 const vec3 ks = make3(fr[3], fr[4], fr[5]);
                 if ((kind & 0xff) == CK_SPEC) {
-                    ret = make3(fr[0], fr[1], fr[2]) + ret * ks; // hitColor += specularColor * ks
+                    Lo = make3(fr[0], fr[1], fr[2]) + ret * ks; // hitColor += specularColor * ks
+                    state = ST_PASS;
+                } else if ((kind & 0xff) == CK_PASS) { // hitColor = hitColor * (1 - transparency) + passColor * transparency
+                    ret = make3(fr[0], fr[1], fr[2]) * (1.f - fr[26]) + ret * fr[26];
                     state = ST_RETURN;
                 } else {
                     const vec3 acc = make3(fr[17], fr[18], fr[19]) + ks * ret; // accumulatedColor += ks * renderRay(...)
@@ -1209,10 +1269,6 @@ int check_features(const rt_features* f)
         rt::set_error("enableTextureMapping is not implemented on the GPU path");
         return RT_ERR_UNSUPPORTED;
     }
-    if (f->enableTransparency) {
-        rt::set_error("enableTransparency is not implemented on the GPU path");
-        return RT_ERR_UNSUPPORTED;
-    }
     if (f->shadingModel < 0 || f->shadingModel > 3) {
         rt::set_error("shadingModel %d out of range", f->shadingModel);
         return RT_ERR_INVALID;
@@ -1433,7 +1489,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
     if (grid > fullGrid) grid = fullGrid;
 
-    if (flags & RT_RENDER_SERIAL) {
+    // pass-through rays and the walk through transparent occluders exist in the depth-first kernel only
+    if ((flags & RT_RENDER_SERIAL) || features->enableTransparency) {
         RenderParams P;
         P.S = scene->view;
         P.cam = *camera;
