@@ -308,7 +308,7 @@ def test_slab_division_is_exact():
 
 def test_error_reporting():
     g, _, sc = scene_pair("cornell")
-    fg, _ = both_features(enableTransparency=1)
+    fg, _ = both_features(enableTextureMapping=1)
     cg, _ = both_cameras(64, 64)
     with pytest.raises(api.RtError) as e:
         g.render_image(cg, fg, 64, 64)
