@@ -7,14 +7,18 @@
 //   * shadow rays never draw from the sampler and never change control flow: they only scale a
 //     term that is added to the pixel;
 //   * rays spawned at rayDepth 6 cannot spawn anything (recursion stops at rayDepth < 6), so with
-//     point lights they draw nothing either.
+//     point lights they draw nothing either;
+//   * the children of a glossy loop at rayDepth 4 each consume either nothing more or exactly 2N draws,
+//     so child i starts at one of i+1 known sampler offsets: all candidates are traced in one round
+//     and the valid ones picked afterwards ("batched" loop).
 // So the path stage walks only the sequential part - the radiance rays whose outcome decides later
-// sampler offsets - in the reference's exact order, one ray per active pixel per round, and emits
-// everything else as independent work.  Every closest-hit query of the frame goes through ONE lean
-// kernel, trace_kernel (ray records in, {t, triangle} out); the kernels around it only generate
-// rays and consume hits:
-//   primary_kernel      camera rays (traced in place: most miss the root box) -> states, round-1 rays
-//   trace_kernel        rays -> hits                                  (runs once per stage)
+// sampler offsets - in the reference's exact order, one ray (or one candidate batch) per active pixel
+// per round, and emits everything else as independent work.  Every closest-hit query of the frame goes
+// through the same two lean kernels (ray records in, {t, triangle} out): trace_kernel, one ray per lane,
+// for stages with many rays, and group_trace_kernel, several lanes per ray, for stages with few rays and
+// for the rays trace_kernel hands over.  The kernels around them only generate rays and consume hits:
+//   camera_kernel       pixel rays; pixels whose ray misses the root box end here -> states, round-1 rays
+//   trace kernels       rays -> hits                                  (once per stage)
 //   path_logic_kernel   hits of round r -> shade tasks, leaf rays, rays of round r+1
 //   leaf_logic_kernel   hits of the deferred last-level rays -> shade tasks
 //   shadow_gen_kernel   shade tasks -> one shadow ray per light sample
@@ -417,11 +421,10 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
 // Path stage: the sequential part of each pixel, one radiance ray per active pixel per round.
 //
 // A pixel's depth-first state lives in HBM between rounds (PathState: a 64-byte header with the ray
-// to trace next + one 80-byte frame per pending glossy loop).  primary_kernel traces the camera rays
-// (pixels fetched tile by tile from a shared counter) and creates a state only for pixels that still
-// have a ray to trace; round_kernel r takes the compact list of active states, traces one ray for
-// each, advances its recursion to the next ray and appends it to the list of round r+1.  Every round
-// therefore runs dense waves, however uneven the pixels' chains are.
+// to trace next + one 80-byte frame per pending glossy loop).  camera_kernel creates a state only for
+// pixels that have a ray to trace; path_logic_kernel r takes the compact list of active states and the
+// hits of their rays, advances each recursion to its next ray (or candidate batch) and appends it to the
+// list of round r+1.  Every round therefore runs dense waves, however uneven the pixels' chains are.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFrameDwords = 20;                                   // 80 B per pending glossy loop
 constexpr int kStateDwords = 16 + RT_MAX_RAY_DEPTH * kFrameDwords; // 544 B
