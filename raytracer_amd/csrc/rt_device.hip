@@ -56,8 +56,10 @@ struct rt_scene {
     uint32_t* d_longList = nullptr; // indices of the rays a one-ray-per-lane launch handed over (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
+    uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
+    uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
-    uint32_t laneModeAbove = 131072; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
+    uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     std::vector<int> lightTypes;
 };
@@ -1411,6 +1413,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) s->groupLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
+    if (const char* e = getenv("RT_AMD_GROUP_BLOCKS")) s->groupBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 0);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->numCUs = cus;
@@ -1666,20 +1670,24 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     uint32_t* const rayCounts = scene->d_roundCounts + kMaxRounds;
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
-    const uint32_t traceGrid = (uint32_t)scene->numCUs * (getenv("RT_AMD_TRACE_BLOCKS") ? (uint32_t)atoi(getenv("RT_AMD_TRACE_BLOCKS")) : 8u);
+    const uint32_t traceGrid = (uint32_t)scene->numCUs * scene->laneBlocksPerCU;
+    // every ray of a group launch (at most laneModeAbove of them) gets its group from the grid position
+    const uint32_t groupRaysPerBlock = kBlock / (scene->groupLanes > 1 ? scene->groupLanes : 8u);
+    const uint32_t groupGrid = scene->groupBlocksPerCU ? (uint32_t)scene->numCUs * scene->groupBlocksPerCU
+                                                       : (scene->laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     auto launch_one = [&](uint32_t groupLanes) {
         T.fetch = scene->d_roundCounts + nextFetch++;
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
     do {                                                                                                                  \
         if (groupLanes == 4)                                                                                              \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);   \
         else if (groupLanes == 8)                                                                                         \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);   \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);   \
         else if (groupLanes == 16)                                                                                        \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);  \
         else if (groupLanes == 32)                                                                                        \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T, reserve);  \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);  \
         else if (stackClass == 0) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
         else if (stackClass == 1) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 24>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
         else hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T);                \
