@@ -1412,7 +1412,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     s->treeDepth = flat.maxDepth;
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
-    if (const char* e = getenv("RT_AMD_GROUP_LANES")) s->groupLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
+        const int g = atoi(e);
+        if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) s->groupLanes = (uint32_t)g;
+    }
     if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     if (const char* e = getenv("RT_AMD_GROUP_BLOCKS")) s->groupBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 0);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
@@ -1702,7 +1705,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // after `stepBudget` steps start again with several lanes per ray, so that the stage does not wait for its few
     // longest rays at one-lane speed.  Few rays: several lanes per ray from the start.  The ray count is only
     // known on the device, so every variant is launched and those whose range does not hold the count return at once.
-    const bool groupOk = features->enableAccelStructure && scene->treeDepth <= 30 && scene->groupLanes > 1;
+    const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;

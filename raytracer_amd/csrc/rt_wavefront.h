@@ -945,7 +945,7 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 // ---------------------------------------------------------------------------------------------
 template <int G>
 struct GroupLayout {
-    static constexpr int kQ = (G <= 16) ? 64 : 4 * G;  // node entries per group
+    static constexpr int kQ = (G <= 4) ? 32 : (G <= 16) ? 64 : 4 * G; // node entries per group
     static constexpr int kStride = kQ + 8;             // skewed so that groups start on different banks
     static constexpr int kLeafQ = 3 * G + 8;           // a node step adds at most 2G leaves to fewer than G
     static constexpr int kNodeWords = 3 * kStride;     // ref[], key[], entry distance[]
@@ -953,7 +953,7 @@ struct GroupLayout {
     static constexpr int kGroupWords = kNodeWords + kLeafWords;
     static constexpr int kGroupsPerBlock = kBlock / G;
     static constexpr int kWords = kGroupsPerBlock * kGroupWords;
-    static constexpr int kMaxTreeDepth = (G <= 16) ? 30 : 31; // deepest tree whose reserve (depth + 2 entries) leaves room to pop G at a time
+    static constexpr int kMaxTreeDepth = kQ - 2 - G < 30 ? kQ - 2 - G : 30; // deepest tree whose reserve (depth + 2 entries) leaves room to pop G at a time
 };
 
 struct GroupLane {
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void group_finish(const SceneView& S, GroupLane& T, c
 // trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
 // full stack can always be walked one entry at a time.
 template <bool CULL, bool COUNT, int G>
-__global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P, const int reserve)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
     using Lay = GroupLayout<G>;
     __shared__ uint32_t s_q[Lay::kWords];
@@ -1176,10 +1176,13 @@ __global__ __launch_bounds__(kBlock) void group_trace_kernel(const TraceParams P
         }
 #pragma unroll 1
         for (int it = 0; it < 4; it++) {
-            const bool wantLeaf = has && (T.lq >= G || (T.nq == 0 && T.lq > 0));
-            const bool wantNode = has && !wantLeaf && T.nq > 0;
-            if (__ballot(wantNode) != 0ull) group_node_step<CULL, COUNT, G>(S, T, q, j, groupShift, reserve, wantNode, tc);
-            if (__ballot(wantLeaf) != 0ull) group_leaf_step<COUNT, G>(S, T, q, j, wantLeaf, tc);
+            // A step costs the wave the same however many groups take part: once one group needs a kind of step, every
+            // group with work of that kind joins in (nodes only while the leaf queue has room for 2G more).
+            const bool needLeaf = has && (T.lq >= G || (T.nq == 0 && T.lq > 0));
+            const bool needNode = has && !needLeaf && T.nq > 0;
+            if (__ballot(needNode) != 0ull)
+                group_node_step<CULL, COUNT, G>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
+            if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull) group_leaf_step<COUNT, G>(S, T, q, j, has && T.lq > 0, tc);
             const bool done = has && T.nq == 0 && T.lq == 0;
             if (__ballot(done) != 0ull) {
                 group_finish<G>(S, T, done);
