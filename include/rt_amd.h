@@ -75,6 +75,11 @@ enum {
     RT_RENDER_COUNT_WORK = 1,  /* flag: also count node-pair steps and triangle tests (slower) */
     RT_RENDER_NO_CULL = 2,     /* flag: visit every box the ray enters, as the reference does
                                   (src/bvh.cpp:289-297), instead of skipping boxes beyond the closest hit */
+    RT_RENDER_REFERENCE_TREE = 8, /* flag: walk only the tree passed to rt_scene_create.  By default closest-hit
+                                  queries first walk a second tree that the library builds over the same triangles
+                                  for traversal cost alone, and accept what they find only when it is provably what
+                                  the reference's walk (src/bvh.cpp:235-370) reports; the rest is traced again in
+                                  the reference's tree.  Results are identical either way. */
     RT_RENDER_SERIAL = 4       /* flag: evaluate each pixel as one depth-first recursion and sum radiance in the
                                   reference's nested float order (src/recursive.cpp:25-83); the default pipeline
                                   defers shadow rays and last-level rays and sums per pixel in fixed point.

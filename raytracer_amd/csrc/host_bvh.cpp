@@ -179,7 +179,7 @@ struct Flattener {
     }
     // Child reference for node i; lays out NodePairs in pre-order and triangles in left-to-right
     // leaf order.  Recursion is bounded by the depth limit checked on entry.
-    uint32_t visit(uint32_t i, uint32_t depth)
+    uint32_t visit(uint32_t i, uint32_t depth, uint32_t route)
     {
         if (status != RT_OK) return kLeafBit;
         if (i >= nNodes) {
@@ -230,6 +230,12 @@ struct Flattener {
                 TriAttr at;
                 precomputeTriangle(p, primIds ? primIds[off + k] : off + k, pl, ed, at);
                 arrayPos.push_back({ off + k, uint32_t(out.triPlane.size()) });
+                out.leafBox.insert(out.leafBox.end(), n.lower, n.lower + 3);
+                out.leafBox.insert(out.leafBox.end(), n.upper, n.upper + 3);
+                out.leafRoute.push_back(route);
+                for (const RefVertex* v : { &p.v0, &p.v1, &p.v2 })
+                    for (int a = 0; a < 3; a++)
+                        if (!(v->position[a] >= nodes[0].lower[a] && v->position[a] <= nodes[0].upper[a])) out.nested = false;
                 out.triPlane.push_back(pl);
                 out.triEdges.push_back(ed);
                 out.triAttr.push_back(at);
@@ -241,6 +247,9 @@ struct Flattener {
             snprintf(msg, msgLen, "flatten: node %u has a child index out of range", i);
             return fail(RT_ERR_INVALID);
         }
+        for (uint32_t c : { l, r })
+            for (int a = 0; a < 3; a++)
+                if (!(nodes[c].lower[a] >= n.lower[a] && nodes[c].upper[a] <= n.upper[a])) out.nested = false;
         const uint32_t pair = uint32_t(out.pairs.size());
         out.pairs.emplace_back();
         NodePair np;
@@ -249,8 +258,8 @@ struct Flattener {
         memcpy(np.lo1, nodes[r].lower, 12);
         memcpy(np.hi1, nodes[r].upper, 12);
         np.pad0 = np.pad1 = 0;
-        np.ref0 = visit(l, depth + 1);
-        np.ref1 = visit(r, depth + 1);
+        np.ref0 = visit(l, depth + 1, route * 2u); // depth <= 32: the marker bit stays inside 32 bits
+        np.ref1 = visit(r, depth + 1, route * 2u + 1u);
         out.pairs[pair] = np;
         return pair;
     }
@@ -272,13 +281,153 @@ int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, ui
     f.seen.assign(nNodes, 0);
     memcpy(out.rootLo, nodes[0].lower, 12);
     memcpy(out.rootHi, nodes[0].upper, 12);
-    out.rootRef = f.visit(0, 1);
+    out.rootRef = f.visit(0, 1, 1u);
     if (f.status != RT_OK) return f.status;
     // Brute-force order (enableAccelStructure off, src/bvh.cpp:351-363) = primitives() array order.
     std::sort(f.arrayPos.begin(), f.arrayPos.end());
     out.bruteOrder.resize(f.arrayPos.size());
     for (size_t i = 0; i < f.arrayPos.size(); i++) out.bruteOrder[i] = f.arrayPos[i].second;
     return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query tree: binned surface-area heuristic over the compact triangles, leaves of at most 4.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct QueryBuilder {
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kLeaf = 4;
+    std::vector<vec3> lo, hi, c;
+    std::vector<uint32_t> idx;
+    std::vector<NodePair>* pairs;
+    uint32_t maxDepth = 0;
+    bool sah = true;
+
+    static float area(const vec3 a, const vec3 b)
+    {
+        const vec3 e = b - a;
+        return e.x * e.y + e.y * e.z + e.z * e.x;
+    }
+    static float comp(const vec3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+    // builds [b, e) of idx; returns the child reference and the subtree's box
+    uint32_t build(uint32_t b, uint32_t e, uint32_t depth, vec3& boxLo, vec3& boxHi)
+    {
+        if (depth > maxDepth) maxDepth = depth;
+        boxLo = splat(FLT_MAX), boxHi = splat(-FLT_MAX);
+        vec3 cLo = splat(FLT_MAX), cHi = splat(-FLT_MAX);
+        for (uint32_t i = b; i < e; i++) {
+            boxLo = gmin(boxLo, lo[idx[i]]), boxHi = gmax(boxHi, hi[idx[i]]);
+            cLo = gmin(cLo, c[idx[i]]), cHi = gmax(cHi, c[idx[i]]);
+        }
+        const uint32_t n = e - b;
+        if (n <= kLeaf) return kLeafBit | (n << kRefCountShift) | b;
+        uint32_t mid = b;
+        if (sah) {
+            float bestCost = FLT_MAX;
+            int bestAxis = -1, bestBin = 0;
+            for (int a = 0; a < 3; a++) {
+                const float c0 = comp(cLo, a), c1 = comp(cHi, a);
+                if (!(c1 > c0)) continue;
+                const float scale = float(kBins) / (c1 - c0);
+                vec3 bl[kBins], bh[kBins];
+                uint32_t bn[kBins];
+                for (int k = 0; k < kBins; k++) bl[k] = splat(FLT_MAX), bh[k] = splat(-FLT_MAX), bn[k] = 0;
+                for (uint32_t i = b; i < e; i++) {
+                    int k = int((comp(c[idx[i]], a) - c0) * scale);
+                    k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                    bl[k] = gmin(bl[k], lo[idx[i]]), bh[k] = gmax(bh[k], hi[idx[i]]), bn[k]++;
+                }
+                float rightArea[kBins];
+                uint32_t rightN[kBins];
+                vec3 rl = splat(FLT_MAX), rh = splat(-FLT_MAX);
+                uint32_t rn = 0;
+                for (int k = kBins - 1; k > 0; k--) {
+                    rl = gmin(rl, bl[k]), rh = gmax(rh, bh[k]), rn += bn[k];
+                    rightArea[k] = rn ? area(rl, rh) : 0.0f, rightN[k] = rn;
+                }
+                vec3 ll = splat(FLT_MAX), lh = splat(-FLT_MAX);
+                uint32_t ln = 0;
+                for (int k = 1; k < kBins; k++) { // split between bin k-1 and bin k
+                    ll = gmin(ll, bl[k - 1]), lh = gmax(lh, bh[k - 1]), ln += bn[k - 1];
+                    if (ln == 0 || rightN[k] == 0) continue;
+                    const float cost = area(ll, lh) * float(ln) + rightArea[k] * float(rightN[k]);
+                    if (cost < bestCost) bestCost = cost, bestAxis = a, bestBin = k;
+                }
+            }
+            if (bestAxis >= 0) {
+                const float c0 = comp(cLo, bestAxis), c1 = comp(cHi, bestAxis);
+                const float scale = float(kBins) / (c1 - c0);
+                const int axis = bestAxis, bin = bestBin;
+                mid = uint32_t(std::partition(idx.begin() + b, idx.begin() + e,
+                                              [&](uint32_t t) {
+                                                  int k = int((comp(c[t], axis) - c0) * scale);
+                                                  k = k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
+                                                  return k < bin;
+                                              })
+                               - idx.begin());
+            }
+        }
+        if (mid == b || mid == e) { // no useful plane: halve along the widest centroid axis
+            const vec3 ext = cHi - cLo;
+            const int a = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+            mid = b + n / 2;
+            std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e,
+                             [&](uint32_t x, uint32_t y) { return comp(c[x], a) < comp(c[y], a); });
+        }
+        const uint32_t pair = uint32_t(pairs->size());
+        pairs->emplace_back();
+        NodePair np;
+        vec3 l0, h0, l1, h1;
+        np.ref0 = build(b, mid, depth + 1, l0, h0);
+        np.ref1 = build(mid, e, depth + 1, l1, h1);
+        np.lo0[0] = l0.x, np.lo0[1] = l0.y, np.lo0[2] = l0.z, np.hi0[0] = h0.x, np.hi0[1] = h0.y, np.hi0[2] = h0.z;
+        np.lo1[0] = l1.x, np.lo1[1] = l1.y, np.lo1[2] = l1.z, np.hi1[0] = h1.x, np.hi1[1] = h1.y, np.hi1[2] = h1.z;
+        np.pad0 = np.pad1 = 0;
+        (*pairs)[pair] = np;
+        return pair;
+    }
+};
+} // namespace
+
+void build_query_tree(const FlatScene& flat, QueryTree& out)
+{
+    out = QueryTree {};
+    const uint32_t n = uint32_t(flat.triPlane.size());
+    // the proof a query needs rests on nested reference boxes and on slab distances that are exact with reciprocals
+    if (n <= QueryBuilder::kLeaf || !flat.nested || !flat.fastBounds || (flat.rootRef & kLeafBit)) return;
+    QueryBuilder qb;
+    qb.lo.resize(n), qb.hi.resize(n), qb.c.resize(n), qb.idx.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const TriEdges& t = flat.triEdges[i];
+        const vec3 v0 = make3(t.v0[0], t.v0[1], t.v0[2]), v1 = make3(t.v1x, t.v1y, t.v1z), v2 = make3(t.v2[0], t.v2[1], t.v2[2]);
+        qb.lo[i] = gmin(gmin(v0, v1), v2), qb.hi[i] = gmax(gmax(v0, v1), v2);
+        qb.c[i] = (qb.lo[i] + qb.hi[i]) * 0.5f;
+        qb.idx[i] = i;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        out.pairs.clear();
+        qb.pairs = &out.pairs;
+        qb.maxDepth = 0;
+        qb.sah = (attempt == 0);
+        for (uint32_t i = 0; i < n; i++) qb.idx[i] = i;
+        vec3 l, h;
+        out.rootRef = qb.build(0, n, 1, l, h);
+        if (qb.maxDepth <= 48) break; // a degenerate heuristic tree: fall back to halving
+    }
+    out.maxDepth = qb.maxDepth;
+    out.triPlane.resize(n), out.triEdges.resize(n), out.cert.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t t = qb.idx[i];
+        out.triPlane[i] = flat.triPlane[t];
+        out.triEdges[i] = flat.triEdges[t];
+        TriCert& c = out.cert[i];
+        memcpy(c.leafLo, &flat.leafBox[6 * size_t(t)], 12);
+        memcpy(c.leafHi, &flat.leafBox[6 * size_t(t) + 3], 12);
+        c.compact = t;
+        c.route = flat.leafRoute[t];
+    }
+    out.usable = true;
 }
 
 } // namespace rt

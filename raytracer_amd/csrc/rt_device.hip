@@ -23,6 +23,8 @@ using namespace rt;
 struct rt_scene {
     int device = 0;
     SceneView view {};
+    SceneView queryView {}; // the same scene with the query tree in place of the reference's (cert != null when usable)
+    uint32_t queryDepth = 0;
     void* d_blob = nullptr; // one allocation holding every scene array
     size_t blobBytes = 0;
     unsigned long long* d_stats = nullptr; // 8 counters
@@ -54,6 +56,7 @@ struct rt_scene {
     size_t hitCap = 0;
     void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
     uint32_t* d_longList = nullptr; // indices of the rays a one-ray-per-lane launch handed over (hitCap entries)
+    uint32_t* d_fallList = nullptr; // indices of the rays a query-tree launch could not settle (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
     uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
@@ -78,9 +81,12 @@ namespace {
 constexpr int kBlock = 256;     // 4 waves per workgroup
 constexpr int kFrameFloats = 28; // per recursion level saved state
 constexpr float kFltMin = 1.17549435e-38f;
+constexpr uint32_t kNoHit = 0xffffffffu;
+constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
+constexpr uint32_t kTraversalDone = 0xffffffffu;
 constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
-constexpr uint32_t kMaxTraceLaunches = 4 * kMaxRounds + 1024; // work counters for the trace launches of one frame
+constexpr uint32_t kMaxTraceLaunches = 6 * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
 constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is followed through (transparent shadows)
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
@@ -268,12 +274,72 @@ __device__ __forceinline__ void pair_test(const float4 a, const float4 b, const 
     hr = box_test_any(c.x, c.y, c.z, c.w, e.x, e.y, R, FLT_MAX, tr, outR);
 }
 
+// The conservative test of the query tree: a box is reported hit unless the approximate slab distances put the
+// ray outside it by more than their error bound.  tl / tr are the approximate entry distances (negative when the
+// origin is inside); a caller may skip a box once tl - R.eps exceeds the closest hit.  Only for rays with R.approx.
+__device__ __forceinline__ void pair_test_loose(const float4 a, const float4 b, const float4 c, const float4 e, const RaySlabs& R, bool& hl,
+                                                bool& hr, float& tl, float& tr)
+{
+    const float uLx = fmaf(a.w, R.r.x, R.nor.x), uLy = fmaf(b.x, R.r.y, R.nor.y), uLz = fmaf(b.y, R.r.z, R.nor.z);
+    const float lLx = fmaf(a.x, R.r.x, R.nor.x), lLy = fmaf(a.y, R.r.y, R.nor.y), lLz = fmaf(a.z, R.r.z, R.nor.z);
+    const float uRx = fmaf(c.w, R.r.x, R.nor.x), uRy = fmaf(e.x, R.r.y, R.nor.y), uRz = fmaf(e.y, R.r.z, R.nor.z);
+    const float lRx = fmaf(c.x, R.r.x, R.nor.x), lRy = fmaf(c.y, R.r.y, R.nor.y), lRz = fmaf(c.z, R.r.z, R.nor.z);
+    tl = fmaxf(fmaxf(fminf(uLx, lLx), fminf(uLy, lLy)), fminf(uLz, lLz));
+    tr = fmaxf(fmaxf(fminf(uRx, lRx), fminf(uRy, lRy)), fminf(uRz, lRz));
+    const float exL = fminf(fminf(fmaxf(uLx, lLx), fmaxf(uLy, lLy)), fmaxf(uLz, lLz));
+    const float exR = fminf(fminf(fmaxf(uRx, lRx), fmaxf(uRy, lRy)), fmaxf(uRz, lRz));
+    const float E = R.eps, E2 = E + E;
+    hl = !(tl > exL + E2) && !(exL < -E);
+    hr = !(tr > exR + E2) && !(exR < -E);
+}
+
+// Does the reference's walk reach the leaf with this box?  True only when that is certain: the leaf's box and,
+// because the reference's boxes are nested, every box above it then pass the reference's test (box_test) whatever
+// the rounding of its slab distances.  The slab intervals of an enclosing box contain the leaf's; the test fails only
+// if the entry distance of one axis exceeds the exit distance of ANOTHER axis (on one axis min <= max holds in any
+// arithmetic) or if a box lies behind the origin, so it is enough that the leaf's approximate distances keep those
+// comparisons clear by a margin above the approximation's and the division's error (bounded per axis as R.eps is
+// for all three, see make_slabs).  Only for rays with R.approx.
+__device__ __forceinline__ bool leaf_surely_visited(const SceneView& S, const TriCert& c, const RaySlabs& R)
+{
+    const float ux = fmaf(c.leafHi[0], R.r.x, R.nor.x), uy = fmaf(c.leafHi[1], R.r.y, R.nor.y), uz = fmaf(c.leafHi[2], R.r.z, R.nor.z);
+    const float lx = fmaf(c.leafLo[0], R.r.x, R.nor.x), ly = fmaf(c.leafLo[1], R.r.y, R.nor.y), lz = fmaf(c.leafLo[2], R.r.z, R.nor.z);
+    const float inx = fminf(ux, lx), iny = fminf(uy, ly), inz = fminf(uz, lz);
+    const float exx = fmaxf(ux, lx), exy = fmaxf(uy, ly), exz = fmaxf(uz, lz);
+    const float k = 2.0f * 9.5367431640625e-7f;
+    const float mx = k * (fabsf(R.o.x) + fmaxf(fabsf(S.rootLo[0]), fabsf(S.rootHi[0]))) * fabsf(R.r.x);
+    const float my = k * (fabsf(R.o.y) + fmaxf(fabsf(S.rootLo[1]), fabsf(S.rootHi[1]))) * fabsf(R.r.y);
+    const float mz = k * (fabsf(R.o.z) + fmaxf(fabsf(S.rootLo[2]), fabsf(S.rootHi[2]))) * fabsf(R.r.z);
+    return exx > mx && exy > my && exz > mz && inx + (mx + my) < exy && inx + (mx + mz) < exz && iny + (my + mx) < exx
+        && iny + (my + mz) < exz && inz + (mz + mx) < exx && inz + (mz + my) < exy;
+}
+
+// The same question answered by the reference's own tests: every box on the way from the root's children down to
+// the leaf (the root box itself is tested when a query starts).
+__device__ __forceinline__ bool leaf_visited_exactly(const SceneView& S, const uint32_t route, const RaySlabs& R)
+{
+    uint32_t ref = S.refRootRef;
+    for (int k = 30 - __clz(route); k >= 0; k--) {
+        if (ref & kLeafBit) return false;
+        const float4* p = reinterpret_cast<const float4*>(S.refPairs + ref);
+        const bool second = (route >> k) & 1u;
+        const float4 a = second ? p[2] : p[0], b = second ? p[3] : p[1];
+        float t;
+        bool outside;
+        if (!box_test_any(a.x, a.y, a.z, a.w, b.x, b.y, R, FLT_MAX, t, outside)) return false;
+        ref = __float_as_uint(b.z);
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ray / triangle with hoisted per-triangle constants (archive symbols trianglePlane,
 // intersectRayWithTriangle, pointInTriangle; declared src/intersect.h:5-12).
 // ---------------------------------------------------------------------------------------------
+// TIES: tieT records the distance at which a second triangle was accepted at exactly the distance of the one held.
+template <bool TIES = false>
 __device__ __forceinline__ void tri_test_plane(const SceneView& S, const uint32_t i, const float4 pl, const vec3 o, const vec3 d, float& t,
-                                               uint32_t& tri)
+                                               uint32_t& tri, float* tieT = nullptr)
 {
     const vec3 n = make3(pl.x, pl.y, pl.z);
     const float tt = (pl.w - dot(o, n)) / dot(d, n);
@@ -287,6 +353,7 @@ __device__ __forceinline__ void tri_test_plane(const SceneView& S, const uint32_
     const vec3 v2 = make3(e3.x, e3.y, e3.z), c2 = make3(e3.w, e4.x, e4.y);
     const bool in0 = dot(c0, p - v0) >= 0.0f, in1 = dot(c1, p - v1) >= 0.0f, in2 = dot(c2, p - v2) >= 0.0f;
     if (in0 && in1 && in2) {
+        if (TIES && tt == t && tri != kNoHit) *tieT = tt;
         t = tt;
         tri = i;
     }
@@ -316,9 +383,9 @@ __device__ __forceinline__ bool point_in_triangle(const EdgeRec& E, const vec3 p
     const bool in0 = dot(c0, p - v0) >= 0.0f, in1 = dot(c1, p - v1) >= 0.0f, in2 = dot(c2, p - v2) >= 0.0f;
     return in0 && in1 && in2;
 }
-template <bool COUNT>
+template <bool COUNT, bool TIES = false>
 __device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t first, const uint32_t cnt, const vec3 o, const vec3 d, float& t,
-                                          uint32_t& tri, TraceCounters& tc)
+                                          uint32_t& tri, TraceCounters& tc, float* tieT = nullptr)
 {
     const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
     for (uint32_t k = 0; k < cnt; k += 4) {
@@ -345,24 +412,36 @@ __device__ __forceinline__ void leaf_test(const SceneView& S, const uint32_t fir
             const EdgeRec E0 = load_edges(S, b);
             const EdgeRec E1 = load_edges(S, c1 ? b + 1 : b);
             const bool i0 = point_in_triangle(E0, d * t0 + o), i1 = point_in_triangle(E1, d * t1 + o);
-            if (c0 && i0) t = t0, tri = b;
-            if (c1 && i1 && t >= t1) t = t1, tri = b + 1;
+            if (c0 && i0) {
+                if (TIES && t0 == t && tri != kNoHit) *tieT = t0;
+                t = t0, tri = b;
+            }
+            if (c1 && i1 && t >= t1) {
+                if (TIES && t1 == t && tri != kNoHit) *tieT = t1;
+                t = t1, tri = b + 1;
+            }
         }
         if (c2 || c3) {
             const EdgeRec E2 = load_edges(S, c2 ? b + 2 : b + 3);
             const EdgeRec E3 = load_edges(S, c3 ? b + 3 : b + 2);
             const bool i2 = point_in_triangle(E2, d * t2 + o), i3 = point_in_triangle(E3, d * t3 + o);
-            if (c2 && i2 && t >= t2) t = t2, tri = b + 2;
-            if (c3 && i3 && t >= t3) t = t3, tri = b + 3;
+            if (c2 && i2 && t >= t2) {
+                if (TIES && t2 == t && tri != kNoHit) *tieT = t2;
+                t = t2, tri = b + 2;
+            }
+            if (c3 && i3 && t >= t3) {
+                if (TIES && t3 == t && tri != kNoHit) *tieT = t3;
+                t = t3, tri = b + 3;
+            }
         }
     }
 }
 
 // The same leaf with one triangle in flight at a time: fewer live registers, for kernels that rely on
 // many resident waves rather than on short steps.
-template <bool COUNT>
+template <bool COUNT, bool TIES = false>
 __device__ __forceinline__ void leaf_test_narrow(const SceneView& S, const uint32_t first, const uint32_t cnt, const vec3 o, const vec3 d, float& t,
-                                                 uint32_t& tri, TraceCounters& tc)
+                                                 uint32_t& tri, TraceCounters& tc, float* tieT = nullptr)
 {
     const float4* planes = reinterpret_cast<const float4*>(S.triPlane) + first;
     for (uint32_t k = 0; k < cnt; k += 4) {
@@ -372,10 +451,10 @@ __device__ __forceinline__ void leaf_test_narrow(const SceneView& S, const uint3
         const float4 p2 = planes[k + (m > 2 ? 2 : 0)];
         const float4 p3 = planes[k + (m > 3 ? 3 : 0)];
         if (COUNT) tc.triTests += (m > 4 ? 4 : m);
-        tri_test_plane(S, first + k, p0, o, d, t, tri);
-        if (m > 1) tri_test_plane(S, first + k + 1, p1, o, d, t, tri);
-        if (m > 2) tri_test_plane(S, first + k + 2, p2, o, d, t, tri);
-        if (m > 3) tri_test_plane(S, first + k + 3, p3, o, d, t, tri);
+        tri_test_plane<TIES>(S, first + k, p0, o, d, t, tri, tieT);
+        if (m > 1) tri_test_plane<TIES>(S, first + k + 1, p1, o, d, t, tri, tieT);
+        if (m > 2) tri_test_plane<TIES>(S, first + k + 2, p2, o, d, t, tri, tieT);
+        if (m > 3) tri_test_plane<TIES>(S, first + k + 3, p3, o, d, t, tri, tieT);
     }
 }
 
@@ -404,9 +483,6 @@ __device__ __forceinline__ bool sphere_test(const GpuSphere& sp, const vec3 o, c
     return true;
 }
 
-constexpr uint32_t kNoHit = 0xffffffffu;
-constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
-constexpr uint32_t kTraversalDone = 0xffffffffu;
 
 // ---------------------------------------------------------------------------------------------
 // Closest hit (reference intersectRayWithBVH, src/bvh.cpp:235-370).  Near child first, ties to the
@@ -1348,10 +1424,14 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         rt::set_error("rt_scene_create: no HIP device available");
         return RT_ERR_HIP;
     }
+    QueryTree qt;
+    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt);
     const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
+    const size_t nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
         + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(nMaterials * sizeof(GpuMaterial))
-        + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + 256;
+        + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQPairs * sizeof(NodePair))
+        + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert)) + 256;
     std::vector<char> host(total, 0);
     char* hp = host.data();
     NodePair* hPairs = carve<NodePair>(hp, nPairs);
@@ -1362,6 +1442,16 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
     GpuLight* hLight = carve<GpuLight>(hp, nLights);
     GpuSphere* hSph = carve<GpuSphere>(hp, nSpheres);
+    NodePair* hQPairs = carve<NodePair>(hp, nQPairs);
+    TriPlane* hQPlane = carve<TriPlane>(hp, nQTris);
+    TriEdges* hQEdges = carve<TriEdges>(hp, nQTris);
+    TriCert* hQCert = carve<TriCert>(hp, nQTris);
+    if (qt.usable) {
+        memcpy(hQPairs, qt.pairs.data(), nQPairs * sizeof(NodePair));
+        memcpy(hQPlane, qt.triPlane.data(), nQTris * sizeof(TriPlane));
+        memcpy(hQEdges, qt.triEdges.data(), nQTris * sizeof(TriEdges));
+        memcpy(hQCert, qt.cert.data(), nQTris * sizeof(TriCert));
+    }
     if (nPairs) memcpy(hPairs, flat.pairs.data(), nPairs * sizeof(NodePair));
     if (nTris) {
         memcpy(hPlane, flat.triPlane.data(), nTris * sizeof(TriPlane));
@@ -1404,12 +1494,27 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.materials = carve<GpuMaterial>(dp, nMaterials);
     V.lights = carve<GpuLight>(dp, nLights);
     V.spheres = carve<GpuSphere>(dp, nSpheres);
+    const NodePair* dQPairs = carve<NodePair>(dp, nQPairs);
+    const TriPlane* dQPlane = carve<TriPlane>(dp, nQTris);
+    const TriEdges* dQEdges = carve<TriEdges>(dp, nQTris);
+    const TriCert* dQCert = carve<TriCert>(dp, nQTris);
+    V.cert = nullptr;
+    V.refPairs = V.pairs, V.refRootRef = flat.rootRef;
     memcpy(V.rootLo, flat.rootLo, 12);
     memcpy(V.rootHi, flat.rootHi, 12);
     V.rootRef = flat.rootRef;
     V.nPairs = uint32_t(nPairs), V.nTris = uint32_t(nTris), V.nMaterials = nMaterials, V.nLights = nLights, V.nSpheres = nSpheres;
     V.fastBounds = flat.fastBounds ? 1u : 0u;
     s->treeDepth = flat.maxDepth;
+    s->queryView = V;
+    if (qt.usable) { // same root box: a query starts with the reference's own root test
+        s->queryView.pairs = dQPairs, s->queryView.triPlane = dQPlane, s->queryView.triEdges = dQEdges, s->queryView.cert = dQCert;
+        s->queryView.rootRef = qt.rootRef, s->queryView.nPairs = uint32_t(nQPairs);
+        s->queryDepth = qt.maxDepth;
+    }
+    if (getenv("RT_AMD_VERBOSE"))
+        fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u%s\n", nTris, nPairs,
+                flat.maxDepth, nQPairs, qt.maxDepth, qt.usable ? "" : " (not used)");
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
@@ -1450,6 +1555,7 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_hits);
     (void)hipFree(s->d_shadowRays);
     (void)hipFree(s->d_longList);
+    (void)hipFree(s->d_fallList);
     delete s;
 }
 
@@ -1606,10 +1712,11 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         if (hitsWanted < scene->leafCap) hitsWanted = scene->leafCap;
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
         if (scene->hitCap < hitsWanted) {
-            (void)hipFree(scene->d_hits), (void)hipFree(scene->d_longList);
-            scene->d_hits = nullptr, scene->d_longList = nullptr, scene->hitCap = 0;
+            (void)hipFree(scene->d_hits), (void)hipFree(scene->d_longList), (void)hipFree(scene->d_fallList);
+            scene->d_hits = nullptr, scene->d_longList = nullptr, scene->d_fallList = nullptr, scene->hitCap = 0;
             RT_HIP(hipMalloc(&scene->d_hits, hitsWanted * sizeof(HitRec)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_longList), hitsWanted * sizeof(uint32_t)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_fallList), hitsWanted * sizeof(uint32_t)));
             scene->hitCap = hitsWanted;
         }
     }
@@ -1631,7 +1738,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
         chain *= nRays;
     }
-    if (chain > kMaxRounds - 1 || 4 * nChunks + 32 > kMaxTraceLaunches - 4 * kMaxRounds) {
+    if (chain > kMaxRounds - 1 || 6 * nChunks + 32 > kMaxTraceLaunches - 6 * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
                       (unsigned long long)chain, kMaxRounds - 1, nChunks);
@@ -1679,8 +1786,18 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const uint32_t groupGrid = scene->groupBlocksPerCU ? (uint32_t)scene->numCUs * scene->groupBlocksPerCU
                                                        : (scene->laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
-    auto launch_one = [&](uint32_t groupLanes) {
+    auto launch_one = [&](uint32_t groupLanes, bool query) {
         T.fetch = scene->d_roundCounts + nextFetch++;
+        T.S = query ? scene->queryView : scene->view;
+        if (query) { // only with culling, without counters, with a tree to walk
+            const int qreserve = (int)scene->queryDepth + 2;
+            if (groupLanes == 4) hipLaunchKernelGGL((group_trace_kernel<true, false, 4, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+            else if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+            else if (groupLanes == 16)
+                hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+            else hipLaunchKernelGGL((trace_kernel<true, false, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+            return;
+        }
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
     do {                                                                                                                  \
         if (groupLanes == 4)                                                                                              \
@@ -1705,27 +1822,40 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // after `stepBudget` steps start again with several lanes per ray, so that the stage does not wait for its few
     // longest rays at one-lane speed.  Few rays: several lanes per ray from the start.  The ray count is only
     // known on the device, so every variant is launched and those whose range does not hold the count return at once.
+    // With a query tree the rays walk that tree first; the few whose result is not provably the reference's are
+    // traced again in the reference's tree.
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
+    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 4 || scene->groupLanes == 8 || scene->groupLanes == 16)
+        && (int)scene->queryDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 48) && !(flags & RT_RENDER_REFERENCE_TREE);
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
         T.indirect = nullptr, T.stepBudget = 0, T.longList = scene->d_longList, T.longCount = nullptr;
+        T.fallList = scene->d_fallList, T.fallCount = nullptr;
         T.runLo = 0, T.runHi = 0xffffffffu;
         if (!groupOk) {
-            launch_one(1);
+            launch_one(1, false);
             return;
         }
         uint32_t* longCount = scene->d_roundCounts + nextFetch++;
+        uint32_t* fallCount = scene->d_roundCounts + nextFetch++;
+        T.fallCount = fallCount;
         T.runLo = scene->laneModeAbove;
         T.stepBudget = count ? 0u : scene->stepBudget, T.longCount = longCount;
-        launch_one(1);
+        launch_one(1, useQuery);
         T.runLo = 0, T.runHi = scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
-        launch_one(scene->groupLanes);
+        launch_one(scene->groupLanes, useQuery);
         if (!count && scene->stepBudget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
             T.indirect = scene->d_longList;
             T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
-            launch_one(scene->groupLanes);
+            launch_one(scene->groupLanes, useQuery);
+        }
+        if (useQuery) { // the unsettled rays, in the reference's tree
+            T.runLo = 0, T.runHi = 0xffffffffu;
+            T.indirect = scene->d_fallList;
+            T.countPtr = fallCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
+            launch_one(scene->groupLanes, false);
         }
     };
 

@@ -66,6 +66,15 @@ struct TriAttr { // 96 B, read once per ray for the final hit (updateHitInfo, sr
 };
 static_assert(sizeof(TriAttr) == 96, "TriAttr layout");
 
+// Per triangle of the query tree (see QueryTree): where the triangle sits in the reference's tree.
+struct TriCert { // 32 B, read once per ray for the closest triangle found
+    float leafLo[3];  // box of the reference leaf that holds the triangle
+    uint32_t compact; // the triangle's index in reference leaf order (TriPlane / TriEdges / TriAttr of the scene)
+    float leafHi[3];
+    uint32_t route;   // the leaf's place in the reference's tree: 1, then one bit per level below the root (1 = second child)
+};
+static_assert(sizeof(TriCert) == 32, "TriCert layout");
+
 struct GpuMaterial { // 32 B
     float kd[3], shininess;
     float ks[3], transparency;
@@ -94,6 +103,9 @@ struct SceneView {
     float rootLo[3], rootHi[3];
     uint32_t rootRef;
     uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
+    const TriCert* cert; // null in the reference-order view; per query-tree triangle otherwise
+    const NodePair* refPairs; // the reference's tree in either view
+    uint32_t refRootRef;
     uint32_t fastBounds; // every box coordinate is 0 or has magnitude in [2^-60, 2^30]: reciprocal-based slab distances are exact
 };
 
@@ -108,7 +120,25 @@ struct FlatScene {
     uint32_t rootRef = 0;
     uint32_t maxDepth = 0;
     bool fastBounds = true;
+    // for the query tree
+    std::vector<float> leafBox; // 6 floats per compact triangle: lower, upper of its reference leaf
+    std::vector<uint32_t> leafRoute; // per compact triangle: TriCert::route of its leaf
+    bool nested = true;         // every child box lies inside its parent's, every triangle inside the root box
 };
+
+// A second tree over the same triangles, built for traversal cost alone (binned surface-area heuristic).  Queries walk
+// it in any order with conservative box tests; what they find is accepted only with a proof that the reference's own
+// walk reports the same triangle (see trace_kernel), otherwise the ray is traced again in the reference's tree.
+struct QueryTree {
+    std::vector<NodePair> pairs;
+    std::vector<TriPlane> triPlane; // copies in query-tree leaf order
+    std::vector<TriEdges> triEdges;
+    std::vector<TriCert> cert;
+    uint32_t rootRef = 0;
+    uint32_t maxDepth = 0;
+    bool usable = false;
+};
+void build_query_tree(const FlatScene& flat, QueryTree& out);
 
 // Returns RT_OK or an error status with `err` describing it.
 int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,

@@ -201,6 +201,8 @@ struct TraceParams {
     uint32_t* longList;       // ... by appending its index here; a launch with several lanes per ray then traces it from the root
     uint32_t* longCount;
     uint32_t* fetch;          // zeroed work counter of this launch
+    uint32_t* fallList;       // query-tree launches: rays whose result could not be proven equal to the reference's are
+    uint32_t* fallCount;      // appended here and traced again in the reference's tree
     unsigned long long* stats;
     uint32_t useBvh;
 };
@@ -213,6 +215,8 @@ struct TraceLane {
     uint32_t cur;  // inner node (pair index), leaf reference, or kTraversalDone
     uint32_t pend; // a leaf reached but not tested yet (0: none)
     int sp;
+    float tieT;    // query tree: distance at which two triangles tied (-1: none)
+    uint32_t lost; // query tree: a stack entry was dropped
 };
 
 // Starts a query.  Returns true when traversal steps remain, false when the query has already ended
@@ -226,6 +230,7 @@ __device__ __forceinline__ bool trace_begin(const SceneView& S, const bool useBv
     T.tri = kNoHit;
     T.sp = 0;
     T.pend = 0;
+    T.tieT = -1.0f, T.lost = 0;
     if (useBvh) {
         float tr;
         bool outside;
@@ -262,15 +267,16 @@ __device__ __forceinline__ void lane_pop(TraceLane& T, const uint32_t* const sta
 }
 
 // One inner node: both child boxes, nearer child next, the other pushed.
-template <bool CULL, bool COUNT, int STACK>
+template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
     const float4* q = reinterpret_cast<const float4*>(S.pairs + T.cur);
     const float4 a = q[0], b = q[1], c = q[2], e = q[3];
     if (COUNT) tc.nodePairs++;
     float tl, trr;
-    bool outL, outR, hl, hr;
-    pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
+    bool outL = true, outR = true, hl, hr;
+    if (QUERY) pair_test_loose(a, b, c, e, T.R, hl, hr, tl, trr);
+    else pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
     const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
     const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
     if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
@@ -283,6 +289,8 @@ __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T,
             // the far child's entry distance, to be compared again when it is popped (0: never culled)
             const bool farOut = leftNear ? outR : outL;
             stack[(STACK + T.sp) * kBlock] = __float_as_uint(farOut ? (leftNear ? trr : tl) - T.R.eps : 0.0f);
+        } else if (QUERY) {
+            T.lost = 1;
         } else {
             tc.overflow++;
         }
@@ -302,10 +310,10 @@ __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T,
 // two that happen to be at a leaf.  Leaves are still tested in the order they are reached, so equal-distance
 // ties fall as in the reference.  Returns true for lanes whose query has ended.
 constexpr int kLeafBatch = 20;
-template <bool CULL, bool COUNT, int STACK>
+template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
-    if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) lane_node_step<CULL, COUNT, STACK>(S, T, stack, tc);
+    if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) lane_node_step<CULL, COUNT, STACK, QUERY>(S, T, stack, tc);
     if (has && T.cur != kTraversalDone && (T.cur & kLeafBit) && T.pend == 0) {
         T.pend = T.cur | kLeafBit;
         lane_pop<CULL, STACK>(T, stack);
@@ -315,16 +323,36 @@ __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool h
     if (__ballot(stuck) != 0ull || __popcll(__ballot(parked)) >= kLeafBatch) {
         if (parked) {
             const uint32_t first = T.pend & kRefOffsetMask, cnt = (T.pend >> kRefCountShift) & kMaxLeafCount;
-            leaf_test_narrow<COUNT>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc);
+            leaf_test_narrow<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc, &T.tieT);
             T.pend = 0;
         }
     }
     if (has && T.cur == kTraversalDone && T.pend == 0) {
-        for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
-            if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
+        if (!QUERY) // a query-tree launch first settles which triangle it reports (see trace_kernel)
+            for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+                if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
         return true;
     }
     return false;
+}
+
+// Query-tree launches: is the closest triangle found what the reference's walk reports?  Yes when no second triangle
+// tied with it (the reference breaks ties by the order of its own walk), no stack entry was lost, and the reference
+// certainly reaches the triangle's leaf - then both walks test that triangle, and the reference, which tests a subset
+// of what the conservative walk tested, can find nothing closer.  On success `tri` becomes the index in reference order.
+__device__ __forceinline__ bool query_result_proven(const SceneView& S, const RaySlabs& R, const float t, uint32_t& tri, const float tieT,
+                                                    const uint32_t lost)
+{
+    if (lost) return false;
+    if (tri == kNoHit) return true; // every triangle the reference tests was tested here too
+    const float4* q = reinterpret_cast<const float4*>(S.cert + tri);
+    const float4 c0 = q[0], c1 = q[1];
+    TriCert c;
+    c.leafLo[0] = c0.x, c.leafLo[1] = c0.y, c.leafLo[2] = c0.z, c.compact = __float_as_uint(c0.w);
+    c.leafHi[0] = c1.x, c.leafHi[1] = c1.y, c.leafHi[2] = c1.z, c.route = __float_as_uint(c1.w);
+    tri = c.compact;
+    if (tieT == t) return false;
+    return leaf_surely_visited(S, c, R) || leaf_visited_exactly(S, c.route, R);
 }
 
 __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
@@ -333,6 +361,7 @@ __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
     T.R.fast = T.R.approx = false;
     T.R.nor = splat(0.0f), T.R.eps = 0.0f;
     T.t = 0.0f, T.tri = kNoHit, T.cur = 0, T.pend = 0, T.sp = 0;
+    T.tieT = -1.0f, T.lost = 0;
 }
 
 #ifndef RT_TRACE_WAVES
@@ -342,7 +371,7 @@ constexpr int kStepsPerCheck = 6; // traversal steps between two looks at the wa
 constexpr uint32_t kLaneChunk = 64;  // rays a wave takes from the shared counter at a time
 constexpr uint32_t kGroupChunk = 32; // the same for a wave whose lanes share rays
 
-template <bool CULL, bool COUNT, int STACK>
+template <bool CULL, bool COUNT, int STACK, bool QUERY = false>
 __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const TraceParams P)
 {
     __shared__ uint32_t s_stack[2 * STACK * kBlock]; // per lane: STACK node references, then their entry distances
@@ -384,6 +413,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
                 chunkNext += min(n, avail);
             }
             first = false;
+            bool unfit = false;
             if (!has) idx = next;
             if (!has && idx < total) {
                 const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
@@ -391,6 +421,11 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
                 has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
                 steps = 0;
                 if (!has) P.hits[idx] = HitRec { T.t, T.tri };
+                if (QUERY && has && !T.R.approx) unfit = true, has = false; // the conservative tests need the approximate slabs
+            }
+            if (QUERY && __ballot(unfit) != 0ull) {
+                const uint32_t pos = wave_fetch(P.fallCount, unfit, lane);
+                if (unfit) P.fallList[pos] = idx;
             }
         }
         if (__ballot(has) == 0ull) {
@@ -399,9 +434,20 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
         }
 #pragma unroll 1
         for (int it = 0; it < kStepsPerCheck; it++) {
-            if (trace_wave_step<CULL, COUNT, STACK>(S, has, T, stack, tc)) {
-                P.hits[idx] = HitRec { T.t, T.tri };
+            const bool ended = trace_wave_step<CULL, COUNT, STACK, QUERY>(S, has, T, stack, tc);
+            bool unproven = false;
+            if (ended) {
+                if (QUERY) {
+                    unproven = !query_result_proven(S, T.R, T.t, T.tri, T.tieT, T.lost);
+                    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+                        if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
+                }
+                if (!unproven) P.hits[idx] = HitRec { T.t, T.tri };
                 has = false;
+            }
+            if (QUERY && __ballot(unproven) != 0ull) {
+                const uint32_t pos = wave_fetch(P.fallCount, unproven, lane);
+                if (unproven) P.fallList[pos] = idx;
             }
         }
         if (budget != 0) { // the few long rays would hold the whole stage at one-lane speed: hand them over
@@ -959,6 +1005,7 @@ struct GroupLayout {
 struct GroupLane {
     RaySlabs R;
     float bestT, cullT; // this lane's best hit; the group's best (for culling)
+    float tieT;         // query tree: distance at which this lane saw two triangles tie (-1: none)
     uint32_t bestKey, bestTri;
     int nq, lq;         // pending nodes / leaves of the group (same value on every lane of the group)
 };
@@ -971,6 +1018,7 @@ __device__ __forceinline__ bool group_begin(const SceneView& S, GroupLane& T, ui
     T.R = make_slabs(S, o, d);
     T.bestT = tmax, T.cullT = tmax;
     T.bestKey = 0, T.bestTri = kNoHit;
+    T.tieT = -1.0f;
     T.nq = 0, T.lq = 0;
     float tr;
     bool outside;
@@ -987,7 +1035,7 @@ __device__ __forceinline__ bool group_begin(const SceneView& S, GroupLane& T, ui
 }
 
 // Node step for the groups with `active`: pop up to G inner nodes, push the children the ray enters.
-template <bool CULL, bool COUNT, int G>
+template <bool CULL, bool COUNT, int G, bool QUERY>
 __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const int groupShift,
                                                 const int reserve, const bool active, TraceCounters& tc)
 {
@@ -1015,8 +1063,9 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
         const float4 a = p[0], b = p[1], c = p[2], e = p[3];
         if (COUNT) tc.nodePairs++;
         float tl, trr;
-        bool outL, outR, hl, hr;
-        pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
+        bool outL = true, outR = true, hl, hr;
+        if (QUERY) pair_test_loose(a, b, c, e, T.R, hl, hr, tl, trr);
+        else pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
         const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
         // the child the reference visits first (src/bvh.cpp:301-310: nearer first, equal distances: right first)
         const bool leftFirst = hl && (!hr || tl < trr);
@@ -1065,7 +1114,7 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
 }
 
 // Leaf step for the groups with `active`: pop up to G leaves, test their triangles, refresh the group's best.
-template <bool COUNT, int G>
+template <bool COUNT, int G, bool QUERY>
 __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const bool active,
                                                 TraceCounters& tc)
 {
@@ -1078,11 +1127,16 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
         const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
         float tl = T.bestT;
         uint32_t tril = kNoHit;
-        leaf_test<COUNT>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc);
+        leaf_test<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
         if (tril != kNoHit) {
-            const uint32_t aligned = key << __clz(key);
-            // tl <= bestT here: a closer hit wins, an equal one wins if the reference meets this leaf later
-            if (tl < T.bestT || aligned > T.bestKey) T.bestT = tl, T.bestKey = aligned, T.bestTri = tril;
+            if (QUERY) { // the walk's order means nothing here: equal distances are only noted
+                if (tl == T.bestT && T.bestTri != kNoHit) T.tieT = tl;
+                T.bestT = tl, T.bestTri = tril;
+            } else {
+                const uint32_t aligned = key << __clz(key);
+                // tl <= bestT here: a closer hit wins, an equal one wins if the reference meets this leaf later
+                if (tl < T.bestT || aligned > T.bestKey) T.bestT = tl, T.bestKey = aligned, T.bestTri = tril;
+            }
         }
     }
     if (active) T.lq -= n;
@@ -1110,9 +1164,31 @@ __device__ __forceinline__ void group_finish(const SceneView& S, GroupLane& T, c
         if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.bestT)) T.bestTri = kSphereBase + s;
 }
 
+// The same for a query-tree launch: the closest triangle of the group, and whether the reference provably reports it
+// (query_result_proven; two lanes holding different triangles at the closest distance are a tie as well).
+template <int G>
+__device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane& T, const int groupShift, const bool active)
+{
+    constexpr uint32_t kGroupMask = (uint32_t)((1ull << G) - 1ull);
+    float bt = T.bestT;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
+    const uint32_t holders = (uint32_t)(__ballot(T.bestTri != kNoHit && T.bestT == bt) >> groupShift) & kGroupMask;
+    const uint32_t tied = (uint32_t)(__ballot(T.tieT == bt) >> groupShift) & kGroupMask;
+    const int winner = holders ? __ffs(holders) - 1 : 0;
+    uint32_t bi = __shfl(T.bestTri, groupShift + winner);
+    if (!holders) bi = kNoHit;
+    if (!active) return true;
+    const bool proven = __popc(holders) <= 1 && tied == 0u && query_result_proven(S, T.R, bt, bi, -1.0f, 0u);
+    T.bestT = bt, T.bestTri = bi;
+    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+        if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.bestT)) T.bestTri = kSphereBase + s;
+    return proven;
+}
+
 // trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
 // full stack can always be walked one entry at a time.
-template <bool CULL, bool COUNT, int G>
+template <bool CULL, bool COUNT, int G, bool QUERY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
     using Lay = GroupLayout<G>;
@@ -1137,6 +1213,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     T.R.fast = T.R.approx = false;
     T.R.nor = splat(0.0f), T.R.eps = 0.0f;
     T.bestT = T.cullT = 0.0f, T.bestKey = 0, T.bestTri = kNoHit, T.nq = T.lq = 0;
+    T.tieT = -1.0f;
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) / G >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has && j == 0);
@@ -1163,11 +1240,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 valid = next < total;
                 idx = (valid && P.indirect) ? P.indirect[next] : next;
             }
+            bool unfit = false;
             if (valid) {
                 const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
                 const float4 a = r[0], b = r[1];
                 has = group_begin<G>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
                 if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
+                if (QUERY && has && !T.R.approx) unfit = true, has = false; // the conservative tests need the approximate slabs
+            }
+            if (QUERY && __ballot(unfit) != 0ull) {
+                const uint32_t pos = wave_fetch(P.fallCount, unfit && j == 0, lane);
+                if (unfit && j == 0) P.fallList[pos] = idx;
             }
         }
         if (__ballot(has) == 0ull) {
@@ -1181,14 +1264,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             const bool needLeaf = has && (T.lq >= G || (T.nq == 0 && T.lq > 0));
             const bool needNode = has && !needLeaf && T.nq > 0;
             if (__ballot(needNode) != 0ull)
-                group_node_step<CULL, COUNT, G>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
-            if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull) group_leaf_step<COUNT, G>(S, T, q, j, has && T.lq > 0, tc);
+                group_node_step<CULL, COUNT, G, QUERY>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
+            if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull)
+                group_leaf_step<COUNT, G, QUERY>(S, T, q, j, has && T.lq > 0, tc);
             const bool done = has && T.nq == 0 && T.lq == 0;
             if (__ballot(done) != 0ull) {
-                group_finish<G>(S, T, done);
+                bool proven = true;
+                if (QUERY) proven = group_finish_query<G>(S, T, groupShift, done);
+                else group_finish<G>(S, T, done);
                 if (done) {
-                    if (j == 0) P.hits[idx] = HitRec { T.bestT, T.bestTri };
+                    if (j == 0 && proven) P.hits[idx] = HitRec { T.bestT, T.bestTri };
                     has = false;
+                }
+                if (QUERY && __ballot(done && !proven) != 0ull) {
+                    const uint32_t pos = wave_fetch(P.fallCount, done && !proven && j == 0, lane);
+                    if (done && !proven && j == 0) P.fallList[pos] = idx;
                 }
             }
         }

@@ -295,6 +295,23 @@ def test_wavefront_matches_serial_and_is_reproducible():
     assert (e < 1e-6).all()
 
 
+@pytest.mark.parametrize("name,W,H,n", [("cornell", 384, 384, 3), ("monkey", 480, 270, 4), ("knot", 384, 216, 4)])
+def test_query_tree_changes_nothing(name, W, H, n):
+    """By default closest-hit queries walk a tree the library builds for speed and keep a result only with a proof
+    that the reference's walk reports the same triangle; RT_RENDER_REFERENCE_TREE walks only the caller's tree.
+    Every query must return the same (t, triangle) either way, so whole frames agree bit for bit - on the Cornell box
+    too, whose coplanar quads and axis-parallel rays are the cases the proof cannot cover."""
+    g, _, _ = scene_pair(name)
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=n)
+    cg, _ = both_cameras(W, H)
+    a = g.render_image(cg, fg, W, H, start_depth=2)
+    b = g.render_image(cg, fg, W, H, start_depth=2, flags=api.RT_RENDER_REFERENCE_TREE)
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32))
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert (a["stats"].primaryRays, a["stats"].shadowRays, a["stats"].secondaryRays) == \
+           (b["stats"].primaryRays, b["stats"].shadowRays, b["stats"].secondaryRays)
+
+
 def test_slab_division_is_exact():
     """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
     total = 0
