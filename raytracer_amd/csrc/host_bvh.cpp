@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -296,7 +297,7 @@ int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, ui
 namespace {
 struct QueryBuilder {
     static constexpr int kBins = 16;
-    static constexpr uint32_t kLeaf = 4;
+    uint32_t kLeaf = 4;
     std::vector<vec3> lo, hi, c;
     std::vector<uint32_t> idx;
     std::vector<NodePair>* pairs;
@@ -395,8 +396,9 @@ void build_query_tree(const FlatScene& flat, QueryTree& out)
     out = QueryTree {};
     const uint32_t n = uint32_t(flat.triPlane.size());
     // the proof a query needs rests on nested reference boxes and on slab distances that are exact with reciprocals
-    if (n <= QueryBuilder::kLeaf || !flat.nested || !flat.fastBounds || (flat.rootRef & kLeafBit)) return;
+    if (n <= 8 || !flat.nested || !flat.fastBounds || (flat.rootRef & kLeafBit)) return;
     QueryBuilder qb;
+    if (const char* e = getenv("RT_AMD_QLEAF")) qb.kLeaf = uint32_t(atoi(e));
     qb.lo.resize(n), qb.hi.resize(n), qb.c.resize(n), qb.idx.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const TriEdges& t = flat.triEdges[i];

@@ -1826,7 +1826,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // traced again in the reference's tree.
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
     const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 4 || scene->groupLanes == 8 || scene->groupLanes == 16)
-        && (int)scene->queryDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 48) && !(flags & RT_RENDER_REFERENCE_TREE);
+        && (int)scene->queryDepth <= (scene->groupLanes == 4 ? GroupLayout<4, false>::kMaxTreeDepth : 48) && !(flags & RT_RENDER_REFERENCE_TREE);
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;

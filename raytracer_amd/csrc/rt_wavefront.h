@@ -989,17 +989,20 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 // one kind of work on all lanes.  A ray that needs several hundred dependent steps on one lane needs a
 // few tens here - the latency of the frame's longest pixel chain shrinks by that factor.
 // ---------------------------------------------------------------------------------------------
-template <int G>
+template <int G, bool KEYS = true>
 struct GroupLayout {
-    static constexpr int kQ = (G <= 4) ? 32 : (G <= 16) ? 64 : 4 * G; // node entries per group
+    // node entries per group; a query-tree launch keeps no order keys and affords 4-lane groups a deeper stack
+    static constexpr int kQ = (G <= 4) ? (KEYS ? 32 : 48) : (G <= 16) ? 64 : 4 * G;
     static constexpr int kStride = kQ + 8;             // skewed so that groups start on different banks
     static constexpr int kLeafQ = 3 * G + 8;           // a node step adds at most 2G leaves to fewer than G
-    static constexpr int kNodeWords = 3 * kStride;     // ref[], key[], entry distance[]
-    static constexpr int kLeafWords = 2 * kLeafQ;      // ref[], key[]
+    static constexpr int kEntryOff = KEYS ? 2 * kStride : kStride; // ref[], (key[],) entry distance[]
+    static constexpr int kNodeWords = kEntryOff + kStride;
+    static constexpr int kLeafWords = (KEYS ? 2 : 1) * kLeafQ; // ref[] (, key[])
     static constexpr int kGroupWords = kNodeWords + kLeafWords;
     static constexpr int kGroupsPerBlock = kBlock / G;
     static constexpr int kWords = kGroupsPerBlock * kGroupWords;
-    static constexpr int kMaxTreeDepth = kQ - 2 - G < 30 ? kQ - 2 - G : 30; // deepest tree whose reserve (depth + 2 entries) leaves room to pop G at a time
+    // deepest tree whose reserve (depth + 2 entries) leaves room to pop G at a time; keys are 32-bit heap indices
+    static constexpr int kMaxTreeDepth = KEYS ? (kQ - 2 - G < 30 ? kQ - 2 - G : 30) : kQ - 2 - G;
 };
 
 struct GroupLane {
@@ -1011,10 +1014,11 @@ struct GroupLane {
 };
 
 // Starts a query on every lane of a group.  Returns true when traversal steps remain.
-template <int G>
+template <int G, bool QUERY>
 __device__ __forceinline__ bool group_begin(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const vec3 o, const vec3 d,
                                             const float tmax)
 {
+    using Lay = GroupLayout<G, !QUERY>;
     T.R = make_slabs(S, o, d);
     T.bestT = tmax, T.cullT = tmax;
     T.bestKey = 0, T.bestTri = kNoHit;
@@ -1025,10 +1029,16 @@ __device__ __forceinline__ bool group_begin(const SceneView& S, GroupLane& T, ui
     // root box against the ray's own t; a miss ends the query before the sphere loop (src/bvh.cpp:264-268)
     if (!box_test_any(S.rootLo[0], S.rootLo[1], S.rootLo[2], S.rootHi[0], S.rootHi[1], S.rootHi[2], T.R, tmax, tr, outside)) return false;
     if (S.rootRef & kLeafBit) {
-        if (j == 0) q[GroupLayout<G>::kNodeWords] = S.rootRef, q[GroupLayout<G>::kNodeWords + GroupLayout<G>::kLeafQ] = 1u;
+        if (j == 0) {
+            q[Lay::kNodeWords] = S.rootRef;
+            if (!QUERY) q[Lay::kNodeWords + Lay::kLeafQ] = 1u;
+        }
         T.lq = 1;
     } else {
-        if (j == 0) q[0] = S.rootRef, q[GroupLayout<G>::kStride] = 1u, q[2 * GroupLayout<G>::kStride] = __float_as_uint(0.0f);
+        if (j == 0) {
+            q[0] = S.rootRef, q[Lay::kEntryOff] = __float_as_uint(0.0f);
+            if (!QUERY) q[Lay::kStride] = 1u;
+        }
         T.nq = 1;
     }
     return true;
@@ -1039,7 +1049,7 @@ template <bool CULL, bool COUNT, int G, bool QUERY>
 __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const int groupShift,
                                                 const int reserve, const bool active, TraceCounters& tc)
 {
-    using Lay = GroupLayout<G>;
+    using Lay = GroupLayout<G, !QUERY>;
     constexpr uint32_t kGroupMask = (uint32_t)((1ull << G) - 1ull);
     uint32_t* const lq = q + Lay::kNodeWords;
     int n = T.nq < G ? T.nq : G;
@@ -1051,8 +1061,8 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
     if (take) {
         const int e = T.nq - 1 - j;
         ref = q[e];
-        key = q[Lay::kStride + e];
-        const float tentry = __uint_as_float(q[2 * Lay::kStride + e]);
+        if (!QUERY) key = q[Lay::kStride + e];
+        const float tentry = __uint_as_float(q[Lay::kEntryOff + e]);
         if (CULL && tentry > T.cullT) take = false;
     }
     bool pushFar = false, pushNear = false;
@@ -1094,19 +1104,23 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
     __builtin_amdgcn_wave_barrier(); // every pop of this step precedes its pushes
     if (farNode) {
         const int e = base + __popc(mFarN & below);
-        q[e] = farRef, q[Lay::kStride + e] = farKey, q[2 * Lay::kStride + e] = __float_as_uint(farT);
+        q[e] = farRef, q[Lay::kEntryOff + e] = __float_as_uint(farT);
+        if (!QUERY) q[Lay::kStride + e] = farKey;
     }
     if (nearNode) { // nearer children on top: they are popped first
         const int e = base + nFarN + __popc(mNearN & below);
-        q[e] = nearRef, q[Lay::kStride + e] = nearKey, q[2 * Lay::kStride + e] = __float_as_uint(nearT);
+        q[e] = nearRef, q[Lay::kEntryOff + e] = __float_as_uint(nearT);
+        if (!QUERY) q[Lay::kStride + e] = nearKey;
     }
     if (farLeaf) {
         const int e = T.lq + __popc(mFarL & below);
-        lq[e] = farRef, lq[Lay::kLeafQ + e] = farKey;
+        lq[e] = farRef;
+        if (!QUERY) lq[Lay::kLeafQ + e] = farKey;
     }
     if (nearLeaf) {
         const int e = T.lq + nFarL + __popc(mNearL & below);
-        lq[e] = nearRef, lq[Lay::kLeafQ + e] = nearKey;
+        lq[e] = nearRef;
+        if (!QUERY) lq[Lay::kLeafQ + e] = nearKey;
     }
     __builtin_amdgcn_wave_barrier();
     T.nq = base + nFarN + __popc(mNearN);
@@ -1118,12 +1132,12 @@ template <bool COUNT, int G, bool QUERY>
 __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const bool active,
                                                 TraceCounters& tc)
 {
-    using Lay = GroupLayout<G>;
+    using Lay = GroupLayout<G, !QUERY>;
     uint32_t* const lq = q + Lay::kNodeWords;
     const int n = T.lq < G ? T.lq : G;
     if (active && j < n) {
         const int e = T.lq - 1 - j;
-        const uint32_t ref = lq[e], key = lq[Lay::kLeafQ + e];
+        const uint32_t ref = lq[e], key = QUERY ? 1u : lq[Lay::kLeafQ + e];
         const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
         float tl = T.bestT;
         uint32_t tril = kNoHit;
@@ -1191,7 +1205,7 @@ __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane
 template <bool CULL, bool COUNT, int G, bool QUERY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
-    using Lay = GroupLayout<G>;
+    using Lay = GroupLayout<G, !QUERY>;
     __shared__ uint32_t s_q[Lay::kWords];
     const SceneView& S = P.S;
     const int lane = threadIdx.x & 63;
@@ -1244,7 +1258,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             if (valid) {
                 const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
                 const float4 a = r[0], b = r[1];
-                has = group_begin<G>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
+                has = group_begin<G, QUERY>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
                 if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
                 if (QUERY && has && !T.R.approx) unfit = true, has = false; // the conservative tests need the approximate slabs
             }
