@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <list>
+#include <memory>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -67,10 +68,15 @@ struct StoredPrim { // Primitive + the index it had in gather order (for canonic
     Primitive p;
     uint32_t orig;
 };
+struct Image { // framework/include/framework/image.h: rows as decoded (top row first), RGB floats
+    int width = 0, height = 0;
+    std::vector<V3> pixels;
+};
 struct Material {
     V3 kd { 0, 0, 0 }, ks { 0, 0, 0 };
     float shininess = 1.0f, transparency = 1.0f;
     int hasTexture = 0;
+    std::shared_ptr<Image> kdTexture; // Material::kdTexture (framework/include/framework/mesh.h:33)
 };
 struct AABB {
     V3 lower { 0, 0, 0 }, upper { 1, 1, 1 };
@@ -439,9 +445,60 @@ bool intersectRayWithBVH(State& st, Ray& ray, HitInfo& hit)
 }
 
 // ------------------------------------------------------------------------------------------
-// Shading (src/shading.cpp:13-233); textures are not restated (sampleMaterialKd returns kd)
+// Textures (src/texture.cpp:5-114)
 // ------------------------------------------------------------------------------------------
-inline V3 sampleMaterialKd(const State&, const HitInfo& h) { return h.material.kd; }
+inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+V3 getPixelFromCoordinates(const Image& image, int xCoord, int yCoord) // src/texture.cpp:5-11: clamped, row-flipped
+{
+    xCoord = clampi(xCoord, 0, image.width - 1);
+    yCoord = clampi(yCoord, 0, image.height - 1);
+    return image.pixels[size_t(image.height - yCoord - 1) * image.width + xCoord];
+}
+V3 sampleTextureNearest(const Image& image, V2 texCoord) // src/texture.cpp:20-34
+{
+    int xCoord = int(floorf(texCoord.x * float(image.width)));
+    int yCoord = int(floorf(texCoord.y * float(image.height)));
+    return getPixelFromCoordinates(image, xCoord, yCoord);
+}
+V3 sampleTextureBilinear(const Image& image, V2 texCoord) // src/texture.cpp:43-114
+{
+    int xTL = int(floorf(texCoord.x * float(image.width)));
+    if (xTL >= image.width) xTL = image.width - 1;
+    else if (texCoord.x * float(image.width) - float(xTL) < 0.5f) --xTL;
+    if (xTL < 0) xTL = 0;
+    int xTR = xTL + 1;
+    if (xTR >= image.width) xTR = xTL;
+    if (xTR < 0) xTR = 0;
+    int yTL = int(floorf(texCoord.y * float(image.height)));
+    if (yTL >= image.height) yTL = image.height - 1;
+    else if (texCoord.y * float(image.height) - float(yTL) < 0.5f) --yTL;
+    if (yTL < 0) yTL = 0;
+    int yBL = yTL + 1;
+    if (yBL >= image.height) yBL = image.height - 1;
+    float xCoord = texCoord.x * float(image.width);
+    if (xCoord >= float(image.width)) xCoord = float(image.width - 1);
+    float yCoord = texCoord.y * float(image.height);
+    if (yCoord >= float(image.height)) yCoord = float(image.height - 1);
+    const float alpha = xCoord - float(xTL) - 0.5f, beta = yCoord - float(yTL) - 0.5f;
+    const float coefTL = (1.f - alpha) * (1.f - beta), coefTR = alpha * (1.f - beta);
+    const float coefBL = (1.f - alpha) * beta, coefBR = alpha * beta;
+    V3 result = getPixelFromCoordinates(image, xTL, yTL) * coefTL;
+    result = result + getPixelFromCoordinates(image, xTR, yTL) * coefTR;
+    result = result + getPixelFromCoordinates(image, xTL, yBL) * coefBL;
+    result = result + getPixelFromCoordinates(image, xTR, yBL) * coefBR;
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------
+// Shading (src/shading.cpp:13-233)
+// ------------------------------------------------------------------------------------------
+V3 sampleMaterialKd(const State& st, const HitInfo& h) // src/shading.cpp:13-24
+{
+    if (st.features.enableTextureMapping && h.material.kdTexture)
+        return st.features.enableBilinearTextureFiltering ? sampleTextureBilinear(*h.material.kdTexture, h.texCoord)
+                                                          : sampleTextureNearest(*h.material.kdTexture, h.texCoord);
+    return h.material.kd;
+}
 
 V3 computeLambertianModel(const State& st, V3, V3 lightDirection, V3 lightColor, const HitInfo& h)
 {
@@ -857,6 +914,57 @@ orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const floa
     return s;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
+int orc_scene_set_texture(orc_scene* s, uint32_t material, const float* rgb, int width, int height)
+{
+    if (!s || material >= s->materials.size()) return 1;
+    if (!rgb) {
+        s->materials[material].kdTexture.reset();
+        return 0;
+    }
+    if (width <= 0 || height <= 0) return 1;
+    auto img = std::make_shared<Image>();
+    img->width = width, img->height = height;
+    img->pixels.resize(size_t(width) * height);
+    for (size_t i = 0; i < img->pixels.size(); i++) img->pixels[i] = v3(rgb + 3 * i);
+    s->materials[material].kdTexture = img;
+    return 0;
+}
+void orc_sample_texture(const float* rgb, int width, int height, int bilinear, const float* uv2, float* out3)
+{
+    Image img;
+    img.width = width, img.height = height;
+    img.pixels.resize(size_t(width) * height);
+    for (size_t i = 0; i < img.pixels.size(); i++) img.pixels[i] = v3(rgb + 3 * i);
+    V2 uv;
+    uv.x = uv2[0], uv.y = uv2[1];
+    put(out3, bilinear ? sampleTextureBilinear(img, uv) : sampleTextureNearest(img, uv));
+}
+void orc_shading_textured(int enableShading, int model, int enableTextureMapping, int bilinear, const float* rgb, int width, int height,
+                          const float* uv2, const float* cam3, const float* light3, const float* lightColor3, const float* normal3,
+                          const float* kd3, const float* ks3, float shininess, float* out3)
+{
+    orc_scene dummy;
+    orc_features f = defaultFeatures();
+    f.enableShading = enableShading;
+    f.shadingModel = model;
+    f.enableTextureMapping = enableTextureMapping;
+    f.enableBilinearTextureFiltering = bilinear;
+    State st { dummy, f, { 0 }, nullptr };
+    HitInfo h;
+    h.normal = v3(normal3);
+    h.texCoord.x = uv2[0], h.texCoord.y = uv2[1];
+    h.material.kd = v3(kd3);
+    h.material.ks = v3(ks3);
+    h.material.shininess = shininess;
+    if (rgb) {
+        auto img = std::make_shared<Image>();
+        img->width = width, img->height = height;
+        img->pixels.resize(size_t(width) * height);
+        for (size_t i = 0; i < img->pixels.size(); i++) img->pixels[i] = v3(rgb + 3 * i);
+        h.material.kdTexture = img;
+    }
+    put(out3, computeShading(st, v3(cam3), v3(light3), v3(lightColor3), h));
+}
 uint32_t orc_bvh_num_nodes(const orc_scene* s) { return uint32_t(s->nodes.size()); }
 uint32_t orc_bvh_num_prims(const orc_scene* s) { return uint32_t(s->prims.size()); }
 uint32_t orc_bvh_num_levels(const orc_scene* s) { return s->numLevels; }

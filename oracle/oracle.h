@@ -6,7 +6,7 @@
  *
  * Pinning status (what the restatement has been checked against):
  *   - sampler, barycentric/interpolation, shading models, light sampling, point-light
- *     visibility logic, reflection rays, glossy basis / disk sampling, bloom filter taps and
+ *     visibility logic, reflection rays, glossy basis / disk sampling, texture sampling, bloom filter taps and
  *     the scene inputs are pinned bit-exactly against the reference's own code, compiled from
  *     its sources (oracle/ref/ref_harness.cpp -> tests/golden/ref_vectors.npz, scenes.npz).
  *   - PARITY UNPINNED: ray/triangle, ray/AABB and ray/sphere arithmetic (the reference ships it
@@ -59,6 +59,9 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const float* materials9, uint32_t nMaterials,
                             const float* lights22, uint32_t nLights, const float* spheres12, uint32_t nSpheres);
 void orc_scene_destroy(orc_scene* s);
+/* Material::kdTexture of mesh `material`: width*height RGB floats, rows as decoded (top row first) - the layout of
+ * Image::pixels (framework/src/image.cpp:33-55).  Null rgb removes it.  Used when enableTextureMapping is set. */
+int orc_scene_set_texture(orc_scene* s, uint32_t material, const float* rgb, int width, int height);
 
 /* BVH in the reference layout: nodes 8 dwords each (incl. the dummy at index 1), primitives 25 dwords
  * each (stored twice per leaf, as the reference does); origIndex = gather index of each stored primitive. */
@@ -89,6 +92,11 @@ void orc_interp_normal(const float* n0, const float* n1, const float* n2, const 
 void orc_interp_uv(const float* t0, const float* t1, const float* t2, const float* bc, float* out2);
 void orc_shading(int enableShading, int model, const float* cam3, const float* light3, const float* lightColor3,
                  const float* normal3, const float* kd3, const float* ks3, float shininess, float* out3);
+/* sampleTextureNearest / sampleTextureBilinear (src/texture.cpp:20-114) and computeShading with sampleMaterialKd. */
+void orc_sample_texture(const float* rgb, int width, int height, int bilinear, const float* uv2, float* out3);
+void orc_shading_textured(int enableShading, int model, int enableTextureMapping, int bilinear, const float* rgb, int width, int height,
+                          const float* uv2, const float* cam3, const float* light3, const float* lightColor3, const float* normal3,
+                          const float* kd3, const float* ks3, float shininess, float* out3);
 void orc_sample_segment(const float* light12, float sample, float* pos3, float* col3);
 void orc_sample_parallelogram(const float* light21, const float* sample2, float* pos3, float* col3);
 /* computeContributionPointLight with the shadow query answered by (hit, tHit); writes the shadow ray issued. */

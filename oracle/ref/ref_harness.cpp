@@ -20,6 +20,8 @@
 #include "sampler.h"
 #include "scene.h"
 #include "shading.h"
+#include "texture.h"
+#include <framework/image.h>
 
 #include <glm/gtc/quaternion.hpp>
 #include <glm/geometric.hpp>
@@ -403,6 +405,72 @@ int main(int argc, char** argv)
         }
         writeF32("luminance_in", in, { 256, 3 });
         writeF32("luminance_out", out, { 256 });
+    }
+
+    // ---------------- texture.cpp + sampleMaterialKd (src/shading.cpp:13-24) ----------------
+    // The image is the reference's own decode of data/default.png (framework/src/image.cpp); a second, odd-sized image
+    // with harness-made texels exercises the clamping and the row flip of getPixelFromCoordinates.
+    {
+        Image img(std::string(DATA_DIR) + "default.png");
+        std::vector<float> px;
+        for (const auto& c : img.pixels) push3(px, c);
+        writeF32("texture_default", px, { (size_t)img.height, (size_t)img.width, 3 });
+        Image odd = img;
+        odd.width = 5, odd.height = 3;
+        odd.pixels.clear();
+        Rng trng(10);
+        for (int i = 0; i < odd.width * odd.height; i++) odd.pixels.push_back(trng.v3(0, 1));
+        std::vector<float> opx;
+        for (const auto& c : odd.pixels) push3(opx, c);
+        writeF32("texture_odd", opx, { (size_t)odd.height, (size_t)odd.width, 3 });
+        Rng rng(11);
+        const size_t N = 2048;
+        std::vector<float> in, outN, outB, outNo, outBo;
+        for (size_t i = 0; i < N; i++) {
+            glm::vec2 uv { rng.uni(0, 1), rng.uni(0, 1) };
+            if (i % 16 == 1) uv = { rng.uni(-0.5f, 1.5f), rng.uni(-0.5f, 1.5f) }; // outside [0,1]: clamped texel coordinates
+            if (i % 16 == 2) uv = { (float)(rng.u32() % 129) / 128.0f, (float)(rng.u32() % 129) / 128.0f }; // texel edges, incl. 1.0
+            if (i % 16 == 3) uv = { ((float)(rng.u32() % 128) + 0.5f) / 128.0f, ((float)(rng.u32() % 128) + 0.5f) / 128.0f }; // texel centres
+            if (i % 16 == 4) uv = { (float)(rng.u32() % 6) / 5.0f, (float)(rng.u32() % 4) / 3.0f };
+            in.push_back(uv.x); in.push_back(uv.y);
+            push3(outN, sampleTextureNearest(img, uv)); push3(outB, sampleTextureBilinear(img, uv));
+            push3(outNo, sampleTextureNearest(odd, uv)); push3(outBo, sampleTextureBilinear(odd, uv));
+        }
+        writeF32("texture_uv", in, { N, 2 });
+        writeF32("texture_default_nearest", outN, { N, 3 });
+        writeF32("texture_default_bilinear", outB, { N, 3 });
+        writeF32("texture_odd_nearest", outNo, { N, 3 });
+        writeF32("texture_odd_bilinear", outBo, { N, 3 });
+        // sampleMaterialKd through computeShading: Lambert and unshaded, texture mapping on / off, both filters
+        std::vector<float> sin_, sout;
+        auto tex = std::make_shared<Image>(odd);
+        for (size_t i = 0; i < 512; i++) {
+            Features f {};
+            f.enableShading = (i % 4) != 0;
+            f.shadingModel = (i % 2) ? ShadingModel::Lambertian : ShadingModel::Phong;
+            f.enableTextureMapping = (i % 8) != 7;
+            f.enableBilinearTextureFiltering = (i % 3) == 0;
+            RenderState state { .scene = scene, .features = f, .bvh = sbvh, .sampler = { 7u } };
+            HitInfo hi;
+            hi.normal = rng.v3(-1, 1);
+            hi.barycentricCoord = glm::vec3(0);
+            hi.texCoord = { rng.uni(0, 1), rng.uni(0, 1) };
+            hi.material.kd = rng.v3(0, 1);
+            hi.material.ks = rng.v3(0, 1);
+            hi.material.shininess = rng.uni(1.0f, 60.0f);
+            hi.material.transparency = 1.0f;
+            const bool hasTex = (i % 5) != 4;
+            if (hasTex) hi.material.kdTexture = tex;
+            glm::vec3 cam = rng.v3(-1, 1), l = rng.v3(-1, 1), lc = rng.v3(0, 1.5f);
+            glm::vec3 r = computeShading(state, cam, l, lc, hi);
+            sin_.insert(sin_.end(), { f.enableShading ? 1.f : 0.f, (float)(int)f.shadingModel, f.enableTextureMapping ? 1.f : 0.f,
+                                      f.enableBilinearTextureFiltering ? 1.f : 0.f, hasTex ? 1.f : 0.f, hi.texCoord.x, hi.texCoord.y });
+            push3(sin_, cam); push3(sin_, l); push3(sin_, lc); push3(sin_, hi.normal);
+            push3(sin_, hi.material.kd); push3(sin_, hi.material.ks); sin_.push_back(hi.material.shininess);
+            push3(sout, r);
+        }
+        writeF32("texshade_in", sin_, { 512, 26 });
+        writeF32("texshade_out", sout, { 512, 3 });
     }
 
     // ---------------- glm semantics used by framework/src/trackball.cpp ----------------

@@ -75,6 +75,10 @@ def lib():
     L.orc_interp_normal.argtypes = [f32p] * 5
     L.orc_interp_uv.argtypes = [f32p] * 5
     L.orc_shading.argtypes = [C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p]
+    L.orc_scene_set_texture.argtypes = [C.c_void_p, C.c_uint32, f32p, C.c_int, C.c_int]
+    L.orc_sample_texture.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p]
+    L.orc_shading_textured.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p,
+                                       f32p, C.c_float, f32p]
     L.orc_sample_segment.argtypes = [f32p, C.c_float, f32p, f32p]
     L.orc_sample_parallelogram.argtypes = [f32p, f32p, f32p, f32p]
     L.orc_point_light.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p, f32p,
@@ -118,7 +122,7 @@ def make_camera(W, H, fov_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20.0, 
 
 
 class OracleScene:
-    def __init__(self, prims, materials, lights, spheres=None):
+    def __init__(self, prims, materials, lights, spheres=None, textures=None):
         L = lib()
         self.prims = np.ascontiguousarray(prims, np.uint32).reshape(-1, 25)
         self.materials = np.ascontiguousarray(materials, np.float32).reshape(-1, 9)
@@ -128,6 +132,10 @@ class OracleScene:
                                     _ptr(self.lights, f32p), len(self.lights), _ptr(self.spheres, f32p), len(self.spheres))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
+        for m, img in (textures or {}).items():  # {mesh index: (H, W, 3) float32, rows as decoded}
+            a = np.ascontiguousarray(img, np.float32)
+            if L.orc_scene_set_texture(self.h, int(m), _ptr(a, f32p), a.shape[1], a.shape[0]) != 0:
+                raise RuntimeError("orc_scene_set_texture failed")
 
     def __del__(self):
         if getattr(self, "h", None):
