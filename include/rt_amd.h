@@ -24,7 +24,7 @@ typedef enum rt_status {
     RT_OK = 0,
     RT_ERR_INVALID = 1,     /* bad argument (null pointer, size mismatch, index out of range) */
     RT_ERR_HIP = 2,         /* a HIP runtime call failed; message holds hipGetErrorString */
-    RT_ERR_UNSUPPORTED = 3, /* a feature flag this build does not implement on the GPU (enableTextureMapping) */
+    RT_ERR_UNSUPPORTED = 3, /* reserved: no feature flag of the path is rejected at present */
     RT_ERR_NOMEM = 4,
     RT_ERR_LIMIT = 5        /* a size beyond a documented limit (tree depth, leaf size, filter size) */
 } rt_status;
@@ -133,7 +133,7 @@ int rt_set_device(int device);
 /* Flatten + upload, once per scene.  Takes what `const BVHInterface&` and `const Scene&` give the
  * reference's renderImage (src/render.h:34): bvh.nodes() (nNodes x 32 B), bvh.primitives()
  * (nPrims x 100 B), per-mesh materials in mesh order as 8 floats {kd3, ks3, shininess, transparency}
- * (framework/include/framework/mesh.h:22-34, textures are not carried), lights as 22 floats
+ * (framework/include/framework/mesh.h:22-34; textures: rt_scene_set_texture), lights as 22 floats
  * {type: 0 point / 1 segment / 2 parallelogram, then the struct's floats, src/common.h:45-60},
  * spheres as 12 floats {center3, radius, kd3, ks3, shininess, transparency} (src/common.h:39-43).
  * primIds (optional, nPrims) = canonical id reported for each stored primitive; null = its index.
@@ -143,6 +143,14 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
                     const float* materials8, uint32_t nMaterials, const float* lights22, uint32_t nLights,
                     const float* spheres12, uint32_t nSpheres, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+
+/* Material::kdTexture of mesh `material` (framework/include/framework/mesh.h:33): width*height RGB floats with the
+ * rows as decoded, top row first - Image::pixels (framework/src/image.cpp:33-55), i.e. `&image.pixels[0].x`.
+ * With enableTextureMapping a hit on that mesh takes its kd from the texture as sampleMaterialKd does
+ * (src/shading.cpp:13-24: sampleTextureNearest / sampleTextureBilinear, src/texture.cpp:5-114, at the interpolated
+ * texture coordinates of updateHitInfo, src/bvh.cpp:36-38).  Null rgb removes the texture.  The texels are copied;
+ * the call waits for frames in flight on the scene's device. */
+int rt_scene_set_texture(rt_scene* scene, uint32_t material, const float* rgb, int width, int height);
 
 /* The per-pixel loop of renderImage (src/render.cpp:27-44) for the rows in `region`:
  * camera ray, renderRays(state, rays, startDepth) (src/recursive.cpp:10-83), Screen::setPixel.

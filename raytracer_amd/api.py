@@ -105,6 +105,7 @@ def lib():
     L.rt_scene_create.argtypes = [vp, C.c_uint32, vp, C.c_uint32, u32p, f32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32,
                                   C.POINTER(vp)]
     L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_set_texture.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_int]
     L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.POINTER(Region), C.c_uint32,
                             vp, vp, vp, vp]
     L.rt_bloom_scratch_bytes.restype = C.c_size_t
@@ -190,7 +191,7 @@ def _p(a, t=C.c_void_p):
 class Scene:
     """Device-resident scene (rt_scene_create) built from reference-layout arrays."""
 
-    def __init__(self, nodes, prims, prim_ids, materials, lights, spheres=None):
+    def __init__(self, nodes, prims, prim_ids, materials, lights, spheres=None, textures=None):
         self.nodes = np.ascontiguousarray(nodes, np.uint32).reshape(-1, 8)
         self.prims = np.ascontiguousarray(prims, np.uint32).reshape(-1, 25)
         self.prim_ids = None if prim_ids is None else np.ascontiguousarray(prim_ids, np.uint32)
@@ -204,14 +205,26 @@ class Scene:
                                     _p(self.materials, f32p), len(self.materials), _p(self.lights, f32p), len(self.lights),
                                     _p(self.spheres, f32p), len(self.spheres), C.byref(h)))
         self.h = h
+        for m, img in (textures or {}).items():
+            self.set_texture(m, img)
 
     @classmethod
-    def from_triangles(cls, prims25, materials, lights, spheres=None):
+    def from_triangles(cls, prims25, materials, lights, spheres=None, textures=None):
         """Scene triangles in gather order -> rt_bvh_build -> rt_scene_create."""
         bvh = Bvh(prims25)
-        s = cls(bvh.nodes(), bvh.primitives(), bvh.primitive_ids(), materials, lights, spheres)
+        s = cls(bvh.nodes(), bvh.primitives(), bvh.primitive_ids(), materials, lights, spheres, textures)
         s.bvh = bvh
         return s
+
+    def set_texture(self, material, image):
+        """Material::kdTexture of mesh `material`: (H, W, 3) float32, rows as decoded (top row first); None removes it."""
+        if image is None:
+            check(lib().rt_scene_set_texture(self.h, int(material), None, 0, 0))
+            return
+        a = np.ascontiguousarray(image, np.float32)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("texture must be (H, W, 3)")
+        check(lib().rt_scene_set_texture(self.h, int(material), _p(a, f32p), a.shape[1], a.shape[0]))
 
     def __del__(self):
         if getattr(self, "h", None):

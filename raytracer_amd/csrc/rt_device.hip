@@ -36,6 +36,8 @@ struct rt_scene {
     float* d_primT = nullptr;
     size_t fbPixels = 0;
     bool hasTextures = false;
+    GpuTexture* d_textures = nullptr;  // one entry per material (part of no blob: rt_scene_set_texture rewrites entries)
+    std::vector<float*> texturePixels; // device copy of each material's texels (null: none)
     uint32_t treeDepth = 0;
     int numCUs = 256;
     // wavefront pipeline buffers (sized on demand by rt_render)
@@ -638,7 +640,74 @@ __device__ __forceinline__ Mat load_material(const SceneView& S, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Shading models (src/shading.cpp:29-233); kd is the material colour (textures not carried)
+// Textures (src/texture.cpp:5-114) and sampleMaterialKd (src/shading.cpp:13-24)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ vec3 texel(const GpuTexture& T, int x, int y) // getPixelFromCoordinates: clamped, rows flipped
+{
+    x = x < 0 ? 0 : (x > T.width - 1 ? T.width - 1 : x);
+    y = y < 0 ? 0 : (y > T.height - 1 ? T.height - 1 : y);
+    const float* q = T.pixels + 3 * ((size_t)(T.height - y - 1) * T.width + x);
+    return make3(q[0], q[1], q[2]);
+}
+__device__ __forceinline__ vec3 texture_nearest(const GpuTexture& T, const vec2 uv)
+{
+    return texel(T, (int)floorf(uv.x * (float)T.width), (int)floorf(uv.y * (float)T.height));
+}
+__device__ __forceinline__ vec3 texture_bilinear(const GpuTexture& T, const vec2 uv)
+{
+    int xTL = (int)floorf(uv.x * (float)T.width);
+    if (xTL >= T.width) xTL = T.width - 1;
+    else if (uv.x * (float)T.width - (float)xTL < 0.5f) --xTL;
+    if (xTL < 0) xTL = 0;
+    int xTR = xTL + 1;
+    if (xTR >= T.width) xTR = xTL;
+    if (xTR < 0) xTR = 0;
+    int yTL = (int)floorf(uv.y * (float)T.height);
+    if (yTL >= T.height) yTL = T.height - 1;
+    else if (uv.y * (float)T.height - (float)yTL < 0.5f) --yTL;
+    if (yTL < 0) yTL = 0;
+    int yBL = yTL + 1;
+    if (yBL >= T.height) yBL = T.height - 1;
+    float xc = uv.x * (float)T.width;
+    if (xc >= (float)T.width) xc = (float)(T.width - 1);
+    float yc = uv.y * (float)T.height;
+    if (yc >= (float)T.height) yc = (float)(T.height - 1);
+    const float alpha = xc - (float)xTL - 0.5f, beta = yc - (float)yTL - 0.5f;
+    const float cTL = (1.f - alpha) * (1.f - beta), cTR = alpha * (1.f - beta), cBL = (1.f - alpha) * beta, cBR = alpha * beta;
+    vec3 r = cTL * texel(T, xTL, yTL);
+    r = r + cTR * texel(T, xTR, yTL);
+    r = r + cBL * texel(T, xTL, yBL);
+    r = r + cBR * texel(T, xTR, yBL);
+    return r;
+}
+// kd of a triangle hit of mesh `mesh` with interpolated texture coordinates uv
+__device__ __forceinline__ vec3 sample_material_kd(const SceneView& S, const rt_features& F, const uint32_t mesh, const vec2 uv, const vec3 kd)
+{
+    if (!F.enableTextureMapping) return kd;
+    const GpuTexture T = S.textures[mesh];
+    if (!T.pixels) return kd;
+    return F.enableBilinearTextureFiltering ? texture_bilinear(T, uv) : texture_nearest(T, uv);
+}
+// interpolateTexCoord at point p of triangle `tri` (updateHitInfo, src/bvh.cpp:18-38): the same operations as fill_hit
+__device__ __forceinline__ vec2 tri_uv_at(const SceneView& S, const uint32_t tri, const vec3 p)
+{
+    const float4* e = reinterpret_cast<const float4*>(S.triEdges + tri);
+    const float4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+    const vec3 v0 = make3(e0.x, e0.y, e0.z), v1 = make3(e1.z, e1.w, e2.x), v2 = make3(e3.x, e3.y, e3.z);
+    const float4* aq = reinterpret_cast<const float4*>(S.triAttr + tri);
+    const float4 a0 = aq[0], a1 = aq[1], a3 = aq[3], a4 = aq[4], a5 = aq[5];
+    const float d00 = a0.z, d01 = a0.w, d11 = a1.x, denom = a1.y;
+    const vec3 first = v1 - v0, second = v2 - v0, point = p - v0;
+    const float d0p = dot(first, point), d1p = dot(second, point);
+    const float beta = (d11 * d0p - d01 * d1p) / denom;
+    const float gamma = (d00 * d1p - d01 * d0p) / denom;
+    const vec3 bary = make3(1.f - beta - gamma, beta, gamma);
+    const vec2 t0 { a3.w, a4.x }, t1 { a4.y, a4.z }, t2 { a4.w, a5.x };
+    return bary.x * t0 + bary.y * t1 + bary.z * t2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shading models (src/shading.cpp:29-233); m.kd is what sampleMaterialKd returns for the hit
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ vec3 lambert(const rt_features& F, const vec3 lightDirection, const vec3 lightColor, const vec3 normal, const Mat& m)
 {
@@ -760,6 +829,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
     vec3 ro = splat(0.0f), rd = splat(0.0f);
     float rt = 0.0f;
     vec3 hn = splat(0.0f);
+    vec2 huv { 0.0f, 0.0f };
     uint32_t hmesh = 0;
     bool hsphere = false;
     vec3 Lo = splat(0.0f);
@@ -842,6 +912,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                 fill_hit(S, F, ttri, ro, rd, rt, h);
                 hn = h.normal;
                 hmesh = h.mesh;
+                huv = h.uv;
                 hsphere = h.isSphere;
                 if (depth == P.startDepth && sampleIdx == 0 && P.primId) P.primId[py * P.W + px] = h.primId;
                 if (depth == P.startDepth && sampleIdx == 0 && P.primT) P.primT[py * P.W + px] = rt;
@@ -935,7 +1006,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                     const bool expected = fabsf(tt - length(ip - lpos)) <= 5e-4f;
                     if (!(intersects && expected)) visible = splat(0.0f);
                 }
-                const Mat m = load_material(S, hmesh, hsphere);
+                Mat m = load_material(S, hmesh, hsphere);
+                if (!hsphere) m.kd = sample_material_kd(S, F, hmesh, huv, m.kd);
                 const GpuLight& L = S.lights[lightIdx];
                 if ((int)L.type == 0) { // computeContributionPointLight (src/light.cpp:151-159)
                     const vec3 p = ro + rt * rd;
@@ -1343,10 +1415,6 @@ void gaussian_taps(uint32_t F, float* taps)
 
 int check_features(const rt_features* f)
 {
-    if (f->enableTextureMapping) {
-        rt::set_error("enableTextureMapping is not implemented on the GPU path");
-        return RT_ERR_UNSUPPORTED;
-    }
     if (f->shadingModel < 0 || f->shadingModel > 3) {
         rt::set_error("shadingModel %d out of range", f->shadingModel);
         return RT_ERR_INVALID;
@@ -1478,6 +1546,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_stats), S_COUNT * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(s->d_stats, 0, S_COUNT * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_work), 256);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
+    if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
+    s->texturePixels.assign(nMaterials, nullptr);
     if (e != hipSuccess) {
         rt::set_error("rt_scene_create: device allocation/upload of %zu bytes failed: %s", total, hipGetErrorString(e));
         rt_scene_destroy(s);
@@ -1494,6 +1565,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.materials = carve<GpuMaterial>(dp, nMaterials);
     V.lights = carve<GpuLight>(dp, nLights);
     V.spheres = carve<GpuSphere>(dp, nSpheres);
+    V.textures = s->d_textures;
     const NodePair* dQPairs = carve<NodePair>(dp, nQPairs);
     const TriPlane* dQPlane = carve<TriPlane>(dp, nQTris);
     const TriEdges* dQEdges = carve<TriEdges>(dp, nQTris);
@@ -1530,9 +1602,40 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     return RT_OK;
 }
 
+int rt_scene_set_texture(rt_scene* scene, uint32_t material, const float* rgb, int width, int height)
+{
+    if (!scene || material >= scene->view.nMaterials || (rgb && (width <= 0 || height <= 0 || (int64_t)width * height > (1 << 28)))) {
+        rt::set_error("rt_scene_set_texture: null scene, material index out of range or empty image");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(hipDeviceSynchronize()); // frames in flight may still read the old texels
+    float* d_px = nullptr;
+    if (rgb) {
+        const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&d_px), bytes));
+        if (hipMemcpy(d_px, rgb, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_px);
+            rt::set_error("rt_scene_set_texture: upload of %zu bytes failed", bytes);
+            return RT_ERR_HIP;
+        }
+    }
+    const GpuTexture t { d_px, rgb ? width : 0, rgb ? height : 0 };
+    if (hipMemcpy(scene->d_textures + material, &t, sizeof(t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d_px);
+        rt::set_error("rt_scene_set_texture: table update failed");
+        return RT_ERR_HIP;
+    }
+    (void)hipFree(scene->texturePixels[material]);
+    scene->texturePixels[material] = d_px;
+    return RT_OK;
+}
+
 void rt_scene_destroy(rt_scene* s)
 {
     if (!s) return;
+    for (float* p : s->texturePixels) (void)hipFree(p);
+    (void)hipFree(s->d_textures);
     (void)hipFree(s->d_blob);
     (void)hipFree(s->d_stats);
     (void)hipFree(s->d_work);

@@ -79,6 +79,10 @@ struct GpuMaterial { // 32 B
     float kd[3], shininess;
     float ks[3], transparency;
 };
+struct GpuTexture { // Material::kdTexture of one mesh (16 B); pixels == null: the mesh has none
+    const float* pixels; // width * height RGB floats, rows as decoded (Image::pixels, framework/src/image.cpp:33-55)
+    int32_t width, height;
+};
 struct GpuLight { // 22 floats + pad = 96 B
     float type;
     float f[21];
@@ -98,6 +102,7 @@ struct SceneView {
     const TriAttr* triAttr;
     const uint32_t* bruteOrder; // compact triangle indices in primitives() array order
     const GpuMaterial* materials;
+    const GpuTexture* textures; // one per material
     const GpuLight* lights;
     const GpuSphere* spheres;
     float rootLo[3], rootHi[3];

@@ -42,7 +42,7 @@ struct ShadeTask { // 64 B
     uint32_t pixel;   // Screen index (H-1-y)*W + x
     uint32_t matInfo; // bit 31: sphere material, low bits: mesh / sphere index
     uint32_t smp;     // sampler state at the start of this hit's light loop (area lights draw from it)
-    uint32_t pad;
+    uint32_t tri;     // the triangle hit (reference leaf order; a sphere index beyond kSphereBase): textured materials look up kd
     float W[3], px;   // weight of this hit's direct light in the pixel; hit point p
     float py, pz, dx, dy; // incoming ray direction d
     float dz, nx, ny, nz; // shading normal
@@ -578,11 +578,11 @@ __device__ __forceinline__ bool glossy_sample(uint32_t& smp, const float radius,
     return !(dot(pd, nrm) <= 0);
 }
 
-__device__ __forceinline__ void store_shade_task(ShadeTask* q, const uint32_t pixel, const uint32_t matInfo, const uint32_t smp, const vec3 W,
-                                                 const vec3 p, const vec3 d, const vec3 n)
+__device__ __forceinline__ void store_shade_task(ShadeTask* q, const uint32_t pixel, const uint32_t matInfo, const uint32_t smp,
+                                                 const uint32_t tri, const vec3 W, const vec3 p, const vec3 d, const vec3 n)
 {
     float4* o = reinterpret_cast<float4*>(q);
-    o[0] = make_float4(__uint_as_float(pixel), __uint_as_float(matInfo), __uint_as_float(smp), 0.0f);
+    o[0] = make_float4(__uint_as_float(pixel), __uint_as_float(matInfo), __uint_as_float(smp), __uint_as_float(tri));
     o[1] = make_float4(W.x, W.y, W.z, p.x);
     o[2] = make_float4(p.y, p.z, d.x, d.y);
     o[3] = make_float4(d.z, n.x, n.y, n.z);
@@ -611,6 +611,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
     LeafTask lt;
     do {
         bool wantShade = false, wantLeaf = false, wantFrames = false, wantBatch = false, wantConsume = false;
+        bool openLoop = false; // push a glossy frame after this pass's shade task has been appended
         while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames && !wantBatch && !wantConsume) {
             switch (L.state) {
             case PS_HIT: {
@@ -630,7 +631,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 st.pixel = L.pixel;
                 st.matInfo = h.mesh | (h.isSphere ? 0x80000000u : 0u);
                 st.smp = L.smp;
-                st.pad = 0;
+                st.tri = L.ttri;
                 st.W[0] = L.curW.x, st.W[1] = L.curW.y, st.W[2] = L.curW.z;
                 st.px = p.x, st.py = p.y, st.pz = p.z;
                 st.dx = L.td.x, st.dy = L.td.y, st.dz = L.td.z;
@@ -656,7 +657,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                             // the frame is parked in the task record's neighbours until storage exists
                             L.to = rorg, L.td = rdir; // reused as scratch: reflection ray of the new loop
                             L.tt = 0.5f / m.shininess;
-                            st.pad = 1; // marks "push a glossy frame after this append"
+                            openLoop = true;
                             // ks and normal are re-read from st / material when the frame is written
                         }
                     }
@@ -734,8 +735,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         }
         // ---- append the tasks produced in this pass (wave-aggregated) ----
         if (__ballot(wantShade) != 0ull) {
-            const bool pushFrame = wantShade && st.pad == 1;
-            st.pad = 0;
+            const bool pushFrame = wantShade && openLoop;
             if (!queue_append(P.shadeQ, P.qCount + 0, P.shadeCap, wantShade, st, lane)) cDrop++;
             // lanes that open a glossy loop need frame storage; allocate for those that have none yet
             if (__ballot(pushFrame && frames == nullptr) != 0ull) allocFrames(pushFrame && frames == nullptr);
@@ -819,7 +819,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     Hit h;
                     fill_hit(S, F, hr.tri, co, cd, hr.t, h);
                     const vec3 p = co + hr.t * cd;
-                    if (room) store_shade_task(P.shadeQ + shadeBase + nShade, L.pixel, h.mesh | (h.isSphere ? 0x80000000u : 0u), L.smp, cw, p, cd, h.normal);
+                    if (room) store_shade_task(P.shadeQ + shadeBase + nShade, L.pixel, h.mesh | (h.isSphere ? 0x80000000u : 0u), L.smp, hr.tri, cw, p, cd, h.normal);
                     nShade++;
                     if (!F.enableReflections) continue;
                     const Mat m = load_material(S, h.mesh, h.isSphere);
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(kBlock) void leaf_logic_kernel(const WaveParams P)
                 const vec3 p = o + hr.t * d;
                 st.pixel = __float_as_uint(b.w);
                 st.matInfo = h.mesh | (h.isSphere ? 0x80000000u : 0u);
-                st.smp = 0, st.pad = 0;
+                st.smp = 0, st.tri = hr.tri;
                 st.W[0] = W.x, st.W[1] = W.y, st.W[2] = W.z;
                 st.px = p.x, st.py = p.y, st.pz = p.z;
                 st.dx = d.x, st.dy = d.y, st.dz = d.z;
@@ -1418,7 +1418,9 @@ __global__ __launch_bounds__(kBlock) void shade_logic_kernel(const WaveParams P)
         const uint32_t pixel = __float_as_uint(a.x), matInfo = __float_as_uint(a.y);
         if (pixel == kHolePixel) continue;
         const vec3 W = make3(b.x, b.y, b.z), p = make3(b.w, c.x, c.y), rd = make3(c.z, c.w, e.x), hn = make3(e.y, e.z, e.w);
-        const Mat m = load_material(S, matInfo & 0x7fffffffu, (matInfo >> 31) != 0);
+        Mat m = load_material(S, matInfo & 0x7fffffffu, (matInfo >> 31) != 0);
+        if (F.enableTextureMapping && !(matInfo >> 31)) // sampleMaterialKd (src/shading.cpp:13-24) at the hit's texture coordinates
+            m.kd = sample_material_kd(S, F, matInfo, tri_uv_at(S, __float_as_uint(a.w), p), m.kd);
         const HitRec* hits = P.hits ? P.hits + (size_t)i * P.raysPerTask : nullptr;
         vec3 Lo = splat(0.0f), areaAcc = splat(0.0f);
         for_each_light_sample(S, F, __float_as_uint(a.z), [&](const uint32_t j, const int type, const bool last, const vec3 lpos, const vec3 lcol) {

@@ -58,6 +58,11 @@ rt_scene* createDeviceScene(std::span<const BVHInterface::Node> nodes, std::span
     check(rt_scene_create(nodes.data(), (uint32_t)nodes.size(), prims.data(), (uint32_t)prims.size(), ids, m8.data(), (uint32_t)mats.size(),
                           l22.data(), (uint32_t)scene.lights.size(), s12.data(), (uint32_t)scene.spheres.size(), &out),
           "rt_scene_create");
+    for (size_t m = 0; m < mats.size(); m++) {
+        const Image* img = mats[m].kdTexture.get();
+        if (img && img->width > 0 && img->height > 0 && img->pixels.size() == size_t(img->width) * size_t(img->height))
+            check(rt_scene_set_texture(out, (uint32_t)m, &img->pixels[0].x, img->width, img->height), "rt_scene_set_texture");
+    }
     return out;
 }
 

@@ -12,13 +12,15 @@
 // build that has glm can alias them.  Everything lives in namespace rtamd.
 //
 // Differences a caller can observe: render calls throw std::runtime_error (message = rt_last_error())
-// when the device path fails - the reference's cannot fail; textures, transparency, depth of field and
-// motion blur are not part of this path (rt_features rejects the first two with RT_ERR_UNSUPPORTED).
+// when the device path fails - the reference's cannot fail; Image holds decoded texels only (the reference's
+// constructor decodes a file with stb_image, which is not part of this path); depth of field and motion blur are
+// not part of this path.
 #pragma once
 #include "../../include/rt_amd.h"
 #include <array>
 #include <cstdint>
 #include <filesystem>
+#include <memory>
 #include <span>
 #include <variant>
 #include <vector>
@@ -34,11 +36,16 @@ struct Vertex {
     vec3 position, normal;
     vec2 texCoord;
 };
+struct Image { // framework/include/framework/image.h:14-24: rows as decoded (top row first)
+    int width = 0, height = 0;
+    std::vector<vec3> pixels;
+};
 struct Material {
     vec3 kd { 1, 1, 1 };
     vec3 ks { 0, 0, 0 };
     float shininess = 1.0f;
     float transparency = 1.0f;
+    std::shared_ptr<Image> kdTexture; // sampled instead of kd when Features::enableTextureMapping is set
 };
 struct Mesh {
     std::vector<Vertex> vertices;

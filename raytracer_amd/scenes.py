@@ -10,6 +10,7 @@ A scene is a dict of arrays in the layout the C ABI takes:
   materials  (M, 9)  float32 kd3 ks3 shininess transparency hasTexture
   lights     (L, 22) float32 type + 21 floats
   spheres    (S, 12) float32
+  textures   {mesh index: (H, W, 3) float32}  Material::kdTexture as Image::pixels (rows as decoded); optional
 """
 import hashlib
 import os
@@ -29,7 +30,13 @@ def preset(name: str) -> dict:
     key = f"scene_{name}_prims"
     if key not in _cache.files:
         raise KeyError(f"unknown preset scene {name!r}")
-    return {k: _cache[f"scene_{name}_{k}"].copy() for k in ("prims", "materials", "lights", "spheres")}
+    sc = {k: _cache[f"scene_{name}_{k}"].copy() for k in ("prims", "materials", "lights", "spheres")}
+    # every preset material with a texture names data/default.png (data/default.mtl:17): the reference's own decode of it
+    tex = [m for m in range(len(sc["materials"])) if sc["materials"][m, 8] != 0.0]
+    if tex:
+        default_png = np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))["texture_default"]
+        sc["textures"] = {m: default_png.copy() for m in tex}
+    return sc
 
 
 def point_light(pos, color=(1.0, 1.0, 1.0)) -> np.ndarray:
@@ -122,10 +129,12 @@ def dragon_standin(n_u: int = 725, n_v: int = 60, seed: int = 7) -> dict:
 def merge(*scenes: dict) -> dict:
     """Concatenates scenes (mesh ids re-based, lights and spheres united): the 'teapot + monkey' configuration."""
     prims, mats, lights, spheres = [], [], [], []
+    textures = {}
     base = 0
     for s in scenes:
         p = s["prims"].copy()
         p[:, 0] += np.uint32(base)
+        textures.update({base + m: img for m, img in s.get("textures", {}).items()})
         base += len(s["materials"])
         prims.append(p)
         mats.append(s["materials"])
@@ -133,8 +142,11 @@ def merge(*scenes: dict) -> dict:
         spheres.append(s["spheres"])
     lights = np.concatenate(lights)
     _, first = np.unique(lights, axis=0, return_index=True)  # a light named by several scenes is kept once
-    return dict(prims=np.concatenate(prims), materials=np.concatenate(mats), lights=lights[np.sort(first)],
-                spheres=np.concatenate(spheres))
+    out = dict(prims=np.concatenate(prims), materials=np.concatenate(mats), lights=lights[np.sort(first)],
+               spheres=np.concatenate(spheres))
+    if textures:
+        out["textures"] = textures
+    return out
 
 
 def mesh_hash(scene: dict) -> str:
@@ -165,7 +177,16 @@ def _parse_mtl(path: str) -> dict:
                 cur["d"] = 1.0 - float(t[1])
             elif t[0] == "map_Kd":
                 cur["tex"] = 1.0
+                cur["map_kd"] = os.path.join(os.path.dirname(os.path.abspath(path)), " ".join(t[1:]))
     return mats
+
+
+def load_image(path: str) -> np.ndarray:
+    """Image::Image (framework/src/image.cpp:33-55): 8-bit RGB / 255.0f, rows as decoded."""
+    from PIL import Image  # decoding only (PNG decodes are exact; JPEG decoders may differ from stb_image in the last bit)
+    with Image.open(path) as im:
+        a = np.asarray(im.convert("RGB"), np.uint8)
+    return (a.astype(np.float32) / np.float32(255.0)).astype(np.float32)
 
 
 def load_obj(path: str, normalize: bool = True, light=(-1.0, 1.0, -1.0)) -> dict:
@@ -236,6 +257,7 @@ def load_obj(path: str, normalize: bool = True, light=(-1.0, 1.0, -1.0)) -> dict
     VN = np.asarray(VN, np.float32).reshape(-1, 3)
     VT = np.asarray(VT, np.float32).reshape(-1, 2)
     out_pos, out_nrm, out_uv, out_id, materials, dedup = [], [], [], [], [], []
+    textures = {}
     for m, (name, faces) in enumerate(meshes):
         f = np.asarray(faces, np.int64)  # (T, 3, 3)
         pos = V[f[:, :, 0]]
@@ -256,6 +278,8 @@ def load_obj(path: str, normalize: bool = True, light=(-1.0, 1.0, -1.0)) -> dict
         dedup.append(pos.reshape(-1, 3)[np.sort(first)])
         mm = mtl.get(name)
         materials.append([1, 1, 1, 0, 0, 0, 1.0, 1.0, 0.0] if mm is None else [*mm["kd"], *mm["ks"], mm["ns"], mm["d"], mm["tex"]])
+        if mm is not None and mm.get("map_kd") and os.path.exists(mm["map_kd"]):
+            textures[m] = load_image(mm["map_kd"])
     pos = np.concatenate(out_pos)
     if normalize:
         allv = np.concatenate(dedup).astype(np.float32)
@@ -264,5 +288,8 @@ def load_obj(path: str, normalize: bool = True, light=(-1.0, 1.0, -1.0)) -> dict
         maxd = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], dtype=np.float32).max()
         pos = ((pos - center) / np.float32(maxd)).astype(np.float32)
     prims = pack_prims(np.concatenate(out_id), pos, np.concatenate(out_nrm), np.concatenate(out_uv))
-    return dict(prims=prims, materials=np.asarray(materials, np.float32), lights=point_light(light)[None, :],
-                spheres=np.zeros((0, 12), np.float32))
+    out = dict(prims=prims, materials=np.asarray(materials, np.float32), lights=point_light(light)[None, :],
+               spheres=np.zeros((0, 12), np.float32))
+    if textures:
+        out["textures"] = textures
+    return out

@@ -39,8 +39,8 @@ _scene_cache = {}
 def scene_pair(name):
     if name not in _scene_cache:
         sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.preset(name)
-        g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
-        o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+        g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
+        o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
         _scene_cache[name] = (g, o, sc)
     return _scene_cache[name]
 
@@ -323,13 +323,64 @@ def test_slab_division_is_exact():
     print("division self-test cases", total)
 
 
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_SERIAL])
+@pytest.mark.parametrize("bilinear", [0, 1])
+@pytest.mark.parametrize("which", ["default.png", "random 37x23"])
+def test_texture_mapping(which, bilinear, flags):
+    """enableTextureMapping: kd from the mesh's texture at the interpolated texture coordinates (src/shading.cpp:13-24,
+    src/texture.cpp, src/bvh.cpp:36-38) on the teapot, whose material names data/default.png - with the reference's
+    decode of that file, and with an odd-sized random image that makes every texel matter.  Mirror bounces and glossy
+    samples carry textured hits through every kind of shade task."""
+    g, o, sc = scene_pair("teapot")
+    assert sc["materials"][0, 8] == 1.0 and 0 in sc["textures"]
+    img = sc["textures"][0] if which == "default.png" else np.random.default_rng(5).random((23, 37, 3), dtype=np.float32)
+    g.set_texture(0, img)
+    O.lib().orc_scene_set_texture(o.h, 0, np.ascontiguousarray(img).ctypes.data_as(O.f32p), img.shape[1], img.shape[0])
+    try:
+        fg, fo = both_features(enableTextureMapping=1, enableBilinearTextureFiltering=bilinear, enableGlossyReflection=1, numGlossySamples=2)
+        cg, co = both_cameras(400, 224, dist=2.0)
+        rg = g.render_image(cg, fg, 400, 224, start_depth=3, flags=flags)
+        ro = o.render(co, fo, 400, 224, start_depth=3)
+        compare_frames(rg, ro, f"teapot textured ({which}, bilinear={bilinear}, flags={flags})")
+        f0, _ = both_features(enableGlossyReflection=1, numGlossySamples=2)
+        plain = g.render_image(cg, f0, 400, 224, start_depth=3, flags=flags)
+        assert np.abs(plain["rgb"] - rg["rgb"]).max() > 0.05  # the texture is really in the picture
+        # unshaded frames return lightColor * sampleMaterialKd (src/shading.cpp:55): exact texels, no powf in the way
+        fg2, fo2 = both_features(enableTextureMapping=1, enableBilinearTextureFiltering=bilinear, enableShading=0, enableReflections=0)
+        a = g.render_image(cg, fg2, 400, 224, flags=flags)
+        b = o.render(co, fo2, 400, 224)
+        assert np.abs(a["rgb"] - b["rgb"]).max() <= 1e-6
+    finally:
+        g.set_texture(0, sc["textures"][0])
+        d = sc["textures"][0]
+        O.lib().orc_scene_set_texture(o.h, 0, d.ctypes.data_as(O.f32p), d.shape[1], d.shape[0])
+
+
+def test_texture_removed_and_untextured_meshes():
+    """A mesh without a texture keeps its kd under enableTextureMapping; removing a texture restores kd."""
+    g, o, sc = scene_pair("monkey")
+    fg, fo = both_features(enableTextureMapping=1)
+    cg, co = both_cameras(320, 180)
+    compare_frames(g.render_image(cg, fg, 320, 180, start_depth=4), o.render(co, fo, 320, 180, start_depth=4), "monkey, texture mapping on, no texture")
+    img = np.random.default_rng(6).random((8, 8, 3), dtype=np.float32)
+    g.set_texture(0, img)
+    with_tex = g.render_image(cg, fg, 320, 180, start_depth=4)
+    g.set_texture(0, None)
+    without = g.render_image(cg, fg, 320, 180, start_depth=4)
+    assert np.abs(with_tex["rgb"] - without["rgb"]).max() > 0.05
+    compare_frames(without, o.render(co, fo, 320, 180, start_depth=4), "monkey, texture removed")
+    with pytest.raises(api.RtError) as e:
+        g.set_texture(5, img)
+    assert e.value.code == api.RT_ERR_INVALID
+
+
 def test_error_reporting():
     g, _, sc = scene_pair("cornell")
-    fg, _ = both_features(enableTextureMapping=1)
     cg, _ = both_cameras(64, 64)
+    fg, _ = both_features(shadingModel=7)
     with pytest.raises(api.RtError) as e:
         g.render_image(cg, fg, 64, 64)
-    assert e.value.code == api.RT_ERR_UNSUPPORTED
+    assert e.value.code == api.RT_ERR_INVALID
     fg2, _ = both_features()
     with pytest.raises(api.RtError) as e:
         g.render_image(cg, fg2, 64, 64, start_depth=7)
