@@ -298,10 +298,13 @@ namespace {
 struct QueryBuilder {
     static constexpr int kBins = 16;
     uint32_t kLeaf = 4;
+    struct BNode { // binary tree of the build; collapsed into Node4 afterwards
+        vec3 lo, hi;
+        uint32_t child[2]; // index into `tree`, or a leaf reference (kLeafBit set)
+    };
     std::vector<vec3> lo, hi, c;
     std::vector<uint32_t> idx;
-    std::vector<NodePair>* pairs;
-    uint32_t maxDepth = 0;
+    std::vector<BNode> tree;
     bool sah = true;
 
     static float area(const vec3 a, const vec3 b)
@@ -311,10 +314,9 @@ struct QueryBuilder {
     }
     static float comp(const vec3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 
-    // builds [b, e) of idx; returns the child reference and the subtree's box
-    uint32_t build(uint32_t b, uint32_t e, uint32_t depth, vec3& boxLo, vec3& boxHi)
+    // builds [b, e) of idx; returns a reference (tree index or leaf) and the subtree's box
+    uint32_t build(uint32_t b, uint32_t e, vec3& boxLo, vec3& boxHi)
     {
-        if (depth > maxDepth) maxDepth = depth;
         boxLo = splat(FLT_MAX), boxHi = splat(-FLT_MAX);
         vec3 cLo = splat(FLT_MAX), cHi = splat(-FLT_MAX);
         for (uint32_t i = b; i < e; i++) {
@@ -376,17 +378,79 @@ struct QueryBuilder {
             std::nth_element(idx.begin() + b, idx.begin() + mid, idx.begin() + e,
                              [&](uint32_t x, uint32_t y) { return comp(c[x], a) < comp(c[y], a); });
         }
-        const uint32_t pair = uint32_t(pairs->size());
-        pairs->emplace_back();
+        const uint32_t me = uint32_t(tree.size());
+        tree.emplace_back();
+        BNode nd;
+        nd.lo = boxLo, nd.hi = boxHi;
+        vec3 l, h;
+        nd.child[0] = build(b, mid, l, h);
+        nd.child[1] = build(mid, e, l, h);
+        tree[me] = nd;
+        return me;
+    }
+
+    // box of a reference of the binary tree
+    void boxOf(uint32_t ref, vec3& l, vec3& h) const
+    {
+        if (ref & kLeafBit) {
+            const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+            l = splat(FLT_MAX), h = splat(-FLT_MAX);
+            for (uint32_t i = first; i < first + cnt; i++) l = gmin(l, lo[idx[i]]), h = gmax(h, hi[idx[i]]);
+        } else {
+            l = tree[ref].lo, h = tree[ref].hi;
+        }
+    }
+
+    // NodePair records in pre-order for binary node `b` (as the reference's tree is laid out); returns the pair index
+    uint32_t emitPairs(uint32_t b, std::vector<NodePair>& out, uint32_t depth, uint32_t& maxDepth) const
+    {
+        if (depth > maxDepth) maxDepth = depth;
+        const uint32_t me = uint32_t(out.size());
+        out.emplace_back();
         NodePair np;
-        vec3 l0, h0, l1, h1;
-        np.ref0 = build(b, mid, depth + 1, l0, h0);
-        np.ref1 = build(mid, e, depth + 1, l1, h1);
-        np.lo0[0] = l0.x, np.lo0[1] = l0.y, np.lo0[2] = l0.z, np.hi0[0] = h0.x, np.hi0[1] = h0.y, np.hi0[2] = h0.z;
-        np.lo1[0] = l1.x, np.lo1[1] = l1.y, np.lo1[2] = l1.z, np.hi1[0] = h1.x, np.hi1[1] = h1.y, np.hi1[2] = h1.z;
+        vec3 l, h;
+        boxOf(tree[b].child[0], l, h);
+        np.lo0[0] = l.x, np.lo0[1] = l.y, np.lo0[2] = l.z, np.hi0[0] = h.x, np.hi0[1] = h.y, np.hi0[2] = h.z;
+        boxOf(tree[b].child[1], l, h);
+        np.lo1[0] = l.x, np.lo1[1] = l.y, np.lo1[2] = l.z, np.hi1[0] = h.x, np.hi1[1] = h.y, np.hi1[2] = h.z;
         np.pad0 = np.pad1 = 0;
-        (*pairs)[pair] = np;
-        return pair;
+        np.ref0 = (tree[b].child[0] & kLeafBit) ? tree[b].child[0] : emitPairs(tree[b].child[0], out, depth + 1, maxDepth);
+        np.ref1 = (tree[b].child[1] & kLeafBit) ? tree[b].child[1] : emitPairs(tree[b].child[1], out, depth + 1, maxDepth);
+        out[me] = np;
+        return me;
+    }
+
+    // Node4 for binary node `b`: its two children, then the inner child with the largest box opened until four
+    uint32_t collapse(uint32_t b, std::vector<Node4>& out, uint32_t depth, uint32_t& maxDepth)
+    {
+        if (depth > maxDepth) maxDepth = depth;
+        uint32_t kids[4] = { tree[b].child[0], tree[b].child[1], kEmptyRef, kEmptyRef };
+        int n = 2;
+        while (n < 4) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int k = 0; k < n; k++) {
+                if (kids[k] & kLeafBit) continue;
+                const float a = area(tree[kids[k]].lo, tree[kids[k]].hi);
+                if (a > bestArea) bestArea = a, best = k;
+            }
+            if (best < 0) break;
+            const uint32_t open = kids[best];
+            kids[best] = tree[open].child[0];
+            kids[n++] = tree[open].child[1];
+        }
+        const uint32_t me = uint32_t(out.size());
+        out.emplace_back();
+        Node4 nd;
+        for (int k = 0; k < 4; k++) {
+            vec3 l = splat(0.0f), h = splat(0.0f);
+            if (k < n) boxOf(kids[k], l, h);
+            nd.lox[k] = l.x, nd.loy[k] = l.y, nd.loz[k] = l.z, nd.hix[k] = h.x, nd.hiy[k] = h.y, nd.hiz[k] = h.z;
+            nd.ref[k] = kEmptyRef, nd.pad[k] = 0;
+        }
+        for (int k = 0; k < n; k++) nd.ref[k] = (kids[k] & kLeafBit) ? kids[k] : collapse(kids[k], out, depth + 1, maxDepth);
+        out[me] = nd;
+        return me;
     }
 };
 } // namespace
@@ -399,25 +463,27 @@ void build_query_tree(const FlatScene& flat, QueryTree& out)
     if (n <= 8 || !flat.nested || !flat.fastBounds || (flat.rootRef & kLeafBit)) return;
     QueryBuilder qb;
     if (const char* e = getenv("RT_AMD_QLEAF")) qb.kLeaf = uint32_t(atoi(e));
+    if (qb.kLeaf < 1 || qb.kLeaf > 8) qb.kLeaf = 4;
     qb.lo.resize(n), qb.hi.resize(n), qb.c.resize(n), qb.idx.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const TriEdges& t = flat.triEdges[i];
         const vec3 v0 = make3(t.v0[0], t.v0[1], t.v0[2]), v1 = make3(t.v1x, t.v1y, t.v1z), v2 = make3(t.v2[0], t.v2[1], t.v2[2]);
         qb.lo[i] = gmin(gmin(v0, v1), v2), qb.hi[i] = gmax(gmax(v0, v1), v2);
         qb.c[i] = (qb.lo[i] + qb.hi[i]) * 0.5f;
-        qb.idx[i] = i;
     }
     for (int attempt = 0; attempt < 2; attempt++) {
-        out.pairs.clear();
-        qb.pairs = &out.pairs;
-        qb.maxDepth = 0;
+        qb.tree.clear();
+        out.nodes.clear();
         qb.sah = (attempt == 0);
         for (uint32_t i = 0; i < n; i++) qb.idx[i] = i;
         vec3 l, h;
-        out.rootRef = qb.build(0, n, 1, l, h);
-        if (qb.maxDepth <= 48) break; // a degenerate heuristic tree: fall back to halving
+        const uint32_t root = qb.build(0, n, l, h); // an inner node: n exceeds the largest leaf
+        out.maxDepth = 0, out.pairDepth = 1; // pairDepth counts levels of nodes as the flattener does: the root is level 1
+        out.rootRef = qb.collapse(root, out.nodes, 1, out.maxDepth);
+        out.pairs.clear();
+        out.pairRootRef = qb.emitPairs(root, out.pairs, 2, out.pairDepth);
+        if (out.pairDepth <= 48) break; // a degenerate heuristic tree: fall back to halving
     }
-    out.maxDepth = qb.maxDepth;
     out.triPlane.resize(n), out.triEdges.resize(n), out.cert.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t t = qb.idx[i];

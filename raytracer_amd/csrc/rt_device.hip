@@ -66,6 +66,7 @@ struct rt_scene {
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
+    uint32_t queryStepBudget = 24;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
     std::vector<int> lightTypes;
 };
 
@@ -293,6 +294,58 @@ __device__ __forceinline__ void pair_test_loose(const float4 a, const float4 b, 
     const float E = R.eps, E2 = E + E;
     hl = !(tl > exL + E2) && !(exL < -E);
     hr = !(tr > exR + E2) && !(exR < -E);
+}
+
+// The conservative test of the query tree, for the four children of one Node4: a box is reported hit unless the
+// approximate slab distances put the ray outside it by more than their error bound, or its entry lies beyond `cullT`
+// by more than that bound.  Result: the children sorted by entry distance, nearest first, as keys = bits of
+// max(entry, 0) with the two lowest bits replaced by the child's slot; kMissKey for the others (they sort last).
+// Only for rays with R.approx.
+constexpr uint32_t kMissKey = 0xffffffffu;
+struct Node4Hits {
+    uint32_t key[4]; // ascending
+    uint32_t ref[4]; // by slot, not sorted: ref[key & 3]
+};
+__device__ __forceinline__ uint32_t node4_ref(const Node4Hits& h, const uint32_t key)
+{
+    const uint32_t k = key & 3u;
+    return k == 0 ? h.ref[0] : (k == 1 ? h.ref[1] : (k == 2 ? h.ref[2] : h.ref[3]));
+}
+__device__ __forceinline__ float node4_entry(const uint32_t key) { return __uint_as_float(key & ~3u); } // rounded towards zero
+__device__ __forceinline__ Node4Hits node4_test(const Node4* node, const RaySlabs& R, const float cullT)
+{
+    const float4* q = reinterpret_cast<const float4*>(node);
+    const float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+    const float4 rf = q[6];
+    Node4Hits h;
+    h.ref[0] = __float_as_uint(rf.x), h.ref[1] = __float_as_uint(rf.y), h.ref[2] = __float_as_uint(rf.z), h.ref[3] = __float_as_uint(rf.w);
+    const float E = R.eps, E2 = E + E;
+    const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+    const float ux[4] = { hix.x, hix.y, hix.z, hix.w }, uy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, uz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float ax = fmaf(lx[k], R.r.x, R.nor.x), bx = fmaf(ux[k], R.r.x, R.nor.x);
+        const float ay = fmaf(ly[k], R.r.y, R.nor.y), by = fmaf(uy[k], R.r.y, R.nor.y);
+        const float az = fmaf(lz[k], R.r.z, R.nor.z), bz = fmaf(uz[k], R.r.z, R.nor.z);
+        const float tin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tex = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const bool hit = h.ref[k] != kEmptyRef && !(tin > tex + E2) && !(tex < -E) && !(tin - E > cullT);
+        h.key[k] = hit ? ((__float_as_uint(fmaxf(tin, 0.0f)) & ~3u) | (uint32_t)k) : kMissKey;
+    }
+    // sorting network for four
+#define RT_CSWAP(a, b)                                   \
+    do {                                                 \
+        const uint32_t lo_ = min(h.key[a], h.key[b]);    \
+        h.key[b] = max(h.key[a], h.key[b]);              \
+        h.key[a] = lo_;                                  \
+    } while (0)
+    RT_CSWAP(0, 1);
+    RT_CSWAP(2, 3);
+    RT_CSWAP(0, 2);
+    RT_CSWAP(1, 3);
+    RT_CSWAP(1, 2);
+#undef RT_CSWAP
+    return h;
 }
 
 // Does the reference's walk reach the leaf with this box?  True only when that is certain: the leaf's box and,
@@ -1495,10 +1548,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     QueryTree qt;
     if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt);
     const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
-    const size_t nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
+    const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
         + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(nMaterials * sizeof(GpuMaterial))
-        + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQPairs * sizeof(NodePair))
+        + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQNodes * sizeof(Node4)) + padded(nQPairs * sizeof(NodePair))
         + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert)) + 256;
     std::vector<char> host(total, 0);
     char* hp = host.data();
@@ -1510,11 +1563,13 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
     GpuLight* hLight = carve<GpuLight>(hp, nLights);
     GpuSphere* hSph = carve<GpuSphere>(hp, nSpheres);
+    Node4* hQNodes = carve<Node4>(hp, nQNodes);
     NodePair* hQPairs = carve<NodePair>(hp, nQPairs);
     TriPlane* hQPlane = carve<TriPlane>(hp, nQTris);
     TriEdges* hQEdges = carve<TriEdges>(hp, nQTris);
     TriCert* hQCert = carve<TriCert>(hp, nQTris);
     if (qt.usable) {
+        memcpy(hQNodes, qt.nodes.data(), nQNodes * sizeof(Node4));
         memcpy(hQPairs, qt.pairs.data(), nQPairs * sizeof(NodePair));
         memcpy(hQPlane, qt.triPlane.data(), nQTris * sizeof(TriPlane));
         memcpy(hQEdges, qt.triEdges.data(), nQTris * sizeof(TriEdges));
@@ -1566,11 +1621,12 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.lights = carve<GpuLight>(dp, nLights);
     V.spheres = carve<GpuSphere>(dp, nSpheres);
     V.textures = s->d_textures;
+    const Node4* dQNodes = carve<Node4>(dp, nQNodes);
     const NodePair* dQPairs = carve<NodePair>(dp, nQPairs);
     const TriPlane* dQPlane = carve<TriPlane>(dp, nQTris);
     const TriEdges* dQEdges = carve<TriEdges>(dp, nQTris);
     const TriCert* dQCert = carve<TriCert>(dp, nQTris);
-    V.cert = nullptr;
+    V.cert = nullptr, V.nodes4 = nullptr;
     V.refPairs = V.pairs, V.refRootRef = flat.rootRef;
     memcpy(V.rootLo, flat.rootLo, 12);
     memcpy(V.rootHi, flat.rootHi, 12);
@@ -1580,15 +1636,17 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     s->treeDepth = flat.maxDepth;
     s->queryView = V;
     if (qt.usable) { // same root box: a query starts with the reference's own root test
-        s->queryView.pairs = dQPairs, s->queryView.triPlane = dQPlane, s->queryView.triEdges = dQEdges, s->queryView.cert = dQCert;
-        s->queryView.rootRef = qt.rootRef, s->queryView.nPairs = uint32_t(nQPairs);
-        s->queryDepth = qt.maxDepth;
+        s->queryView.pairs = dQPairs, s->queryView.nodes4 = dQNodes;
+        s->queryView.triPlane = dQPlane, s->queryView.triEdges = dQEdges, s->queryView.cert = dQCert;
+        s->queryView.rootRef = qt.pairRootRef, s->queryView.nPairs = uint32_t(nQPairs); // root of the 4-wide form: node 0
+        s->queryDepth = qt.pairDepth;
     }
     if (getenv("RT_AMD_VERBOSE"))
-        fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u%s\n", nTris, nPairs,
-                flat.maxDepth, nQPairs, qt.maxDepth, qt.usable ? "" : " (not used)");
+        fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s\n",
+                nTris, nPairs, flat.maxDepth, nQPairs, qt.pairDepth, nQNodes, qt.maxDepth, qt.usable ? "" : " (not used)");
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
         const int g = atoi(e);
         if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) s->groupLanes = (uint32_t)g;
@@ -1892,10 +1950,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     auto launch_one = [&](uint32_t groupLanes, bool query) {
         T.fetch = scene->d_roundCounts + nextFetch++;
         T.S = query ? scene->queryView : scene->view;
-        if (query) { // only with culling, without counters, with a tree to walk
+        if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
-            if (groupLanes == 4) hipLaunchKernelGGL((group_trace_kernel<true, false, 4, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
-            else if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+            if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
             else if (groupLanes == 16)
                 hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
             else hipLaunchKernelGGL((trace_kernel<true, false, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
@@ -1928,8 +1985,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // With a query tree the rays walk that tree first; the few whose result is not provably the reference's are
     // traced again in the reference's tree.
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
-    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 4 || scene->groupLanes == 8 || scene->groupLanes == 16)
-        && (int)scene->queryDepth <= (scene->groupLanes == 4 ? GroupLayout<4, false>::kMaxTreeDepth : 48) && !(flags & RT_RENDER_REFERENCE_TREE);
+    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
+        && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
@@ -1944,11 +2001,12 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint32_t* fallCount = scene->d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
         T.runLo = scene->laneModeAbove;
-        T.stepBudget = count ? 0u : scene->stepBudget, T.longCount = longCount;
+        const uint32_t budget = count ? 0u : (useQuery ? scene->queryStepBudget : scene->stepBudget);
+        T.stepBudget = budget, T.longCount = longCount;
         launch_one(1, useQuery);
         T.runLo = 0, T.runHi = scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
         launch_one(scene->groupLanes, useQuery);
-        if (!count && scene->stepBudget) { // the handed-over rays (none unless the first launch ran)
+        if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
             T.indirect = scene->d_longList;
             T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;

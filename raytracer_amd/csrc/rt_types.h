@@ -66,6 +66,16 @@ struct TriAttr { // 96 B, read once per ray for the final hit (updateHitInfo, sr
 };
 static_assert(sizeof(TriAttr) == 96, "TriAttr layout");
 
+// Inner node of the query tree: up to four children, boxes stored per coordinate so that one lane tests all four with
+// vector loads.  An unused slot holds kEmptyRef.  128 B, 128-B aligned.
+constexpr uint32_t kEmptyRef = 0xffffffffu;
+struct Node4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t ref[4]; // as NodePair::ref, an inner reference being a Node4 index
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "Node4 layout");
+
 // Per triangle of the query tree (see QueryTree): where the triangle sits in the reference's tree.
 struct TriCert { // 32 B, read once per ray for the closest triangle found
     float leafLo[3];  // box of the reference leaf that holds the triangle
@@ -109,6 +119,7 @@ struct SceneView {
     uint32_t rootRef;
     uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
     const TriCert* cert; // null in the reference-order view; per query-tree triangle otherwise
+    const Node4* nodes4; // query view: the query tree with four children per node, root = node 0 (`pairs` holds its binary form)
     const NodePair* refPairs; // the reference's tree in either view
     uint32_t refRootRef;
     uint32_t fastBounds; // every box coordinate is 0 or has magnitude in [2^-60, 2^30]: reciprocal-based slab distances are exact
@@ -135,7 +146,9 @@ struct FlatScene {
 // it in any order with conservative box tests; what they find is accepted only with a proof that the reference's own
 // walk reports the same triangle (see trace_kernel), otherwise the ray is traced again in the reference's tree.
 struct QueryTree {
-    std::vector<NodePair> pairs;
+    std::vector<NodePair> pairs; // the tree as built (two children per node): launches with several lanes per ray
+    std::vector<Node4> nodes;    // the same tree with up to four children per node: one ray per lane
+    uint32_t pairRootRef = 0, pairDepth = 0;
     std::vector<TriPlane> triPlane; // copies in query-tree leaf order
     std::vector<TriEdges> triEdges;
     std::vector<TriCert> cert;

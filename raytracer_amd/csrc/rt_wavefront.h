@@ -267,16 +267,15 @@ __device__ __forceinline__ void lane_pop(TraceLane& T, const uint32_t* const sta
 }
 
 // One inner node: both child boxes, nearer child next, the other pushed.
-template <bool CULL, bool COUNT, int STACK, bool QUERY>
+template <bool CULL, bool COUNT, int STACK>
 __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
     const float4* q = reinterpret_cast<const float4*>(S.pairs + T.cur);
     const float4 a = q[0], b = q[1], c = q[2], e = q[3];
     if (COUNT) tc.nodePairs++;
     float tl, trr;
-    bool outL = true, outR = true, hl, hr;
-    if (QUERY) pair_test_loose(a, b, c, e, T.R, hl, hr, tl, trr);
-    else pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
+    bool outL, outR, hl, hr;
+    pair_test(a, b, c, e, T.R, hl, hr, tl, trr, outL, outR);
     const uint32_t ref0 = __float_as_uint(b.z), ref1 = __float_as_uint(e.z);
     const bool leftNear = tl < trr; // only used when both boxes are hit; equal distances: right first (src/bvh.cpp:301-310)
     if (CULL) { // the distances may be the approximate ones: cull only beyond their error bound
@@ -289,8 +288,6 @@ __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T,
             // the far child's entry distance, to be compared again when it is popped (0: never culled)
             const bool farOut = leftNear ? outR : outL;
             stack[(STACK + T.sp) * kBlock] = __float_as_uint(farOut ? (leftNear ? trr : tl) - T.R.eps : 0.0f);
-        } else if (QUERY) {
-            T.lost = 1;
         } else {
             tc.overflow++;
         }
@@ -300,6 +297,29 @@ __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T,
         T.cur = hl ? ref0 : ref1;
     } else {
         lane_pop<CULL, STACK>(T, stack);
+    }
+}
+
+// The same for a query-tree launch: one 4-wide node, nearest child next, the others pushed farthest first.
+template <int STACK>
+__device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T, uint32_t* const stack)
+{
+    const Node4Hits h = node4_test(S.nodes4 + T.cur, T.R, T.t);
+    if (h.key[0] == kMissKey) {
+        lane_pop<true, STACK>(T, stack);
+        return;
+    }
+    T.cur = node4_ref(h, h.key[0]);
+#pragma unroll
+    for (int k = 3; k >= 1; k--) {
+        if (h.key[k] == kMissKey) continue;
+        if (T.sp < STACK) {
+            stack[T.sp * kBlock] = node4_ref(h, h.key[k]);
+            stack[(STACK + T.sp) * kBlock] = __float_as_uint(node4_entry(h.key[k]) - T.R.eps);
+        } else {
+            T.lost = 1;
+        }
+        T.sp++;
     }
 }
 
@@ -313,7 +333,10 @@ constexpr int kLeafBatch = 20;
 template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
-    if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) lane_node_step<CULL, COUNT, STACK, QUERY>(S, T, stack, tc);
+    if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) {
+        if (QUERY) lane_node4_step<STACK>(S, T, stack);
+        else lane_node_step<CULL, COUNT, STACK>(S, T, stack, tc);
+    }
     if (has && T.cur != kTraversalDone && (T.cur & kLeafBit) && T.pend == 0) {
         T.pend = T.cur | kLeafBit;
         lane_pop<CULL, STACK>(T, stack);
