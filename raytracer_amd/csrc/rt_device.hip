@@ -1151,7 +1151,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                     // sampleDisk (src/extra.cpp:443-450): two draws per sample, consumed even if rejected
                     const float r = radius * sqrtf(sampler_next(smp));
                     const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
-                    const float dx = r * cosf(angle), dy = r * sinf(angle);
+                    float sn, cs;
+                    sincosf(angle, &sn, &cs);
+                    const float dx = r * cs, dy = r * sn;
                     const vec3 pd = normalize(w + dx * u + dy * v);
                     lightSample++;
                     if (dot(pd, nrm) <= 0) continue;

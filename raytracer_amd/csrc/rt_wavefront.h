@@ -329,7 +329,10 @@ __device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T
 // stack is empty) - a wave then runs the long triangle code for many lanes at once instead of for the one or
 // two that happen to be at a leaf.  Leaves are still tested in the order they are reached, so equal-distance
 // ties fall as in the reference.  Returns true for lanes whose query has ended.
-constexpr int kLeafBatch = 20;
+#ifndef RT_LEAF_BATCH
+#define RT_LEAF_BATCH 20
+#endif
+constexpr int kLeafBatch = RT_LEAF_BATCH;
 template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
@@ -390,7 +393,10 @@ __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES
 #endif
-constexpr int kStepsPerCheck = 6; // traversal steps between two looks at the wave's idle lanes
+#ifndef RT_STEPS_PER_CHECK
+#define RT_STEPS_PER_CHECK 6
+#endif
+constexpr int kStepsPerCheck = RT_STEPS_PER_CHECK; // traversal steps between two looks at the wave's idle lanes
 constexpr uint32_t kLaneChunk = 64;  // rays a wave takes from the shared counter at a time
 constexpr uint32_t kGroupChunk = 32; // the same for a wave whose lanes share rays
 
@@ -596,7 +602,9 @@ __device__ __forceinline__ bool glossy_sample(uint32_t& smp, const float radius,
 {
     const float r = radius * sqrtf(sampler_next(smp));
     const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
-    const float dx = r * cosf(angle), dy = r * sinf(angle);
+    float sn, cs;
+    sincosf(angle, &sn, &cs);
+    const float dx = r * cs, dy = r * sn;
     pd = normalize(w + dx * u + dy * v);
     return !(dot(pd, nrm) <= 0);
 }
@@ -706,7 +714,9 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     // sampleDisk (src/extra.cpp:443-450): two draws per sample, consumed even if rejected
                     const float r = radius * sqrtf(sampler_next(L.smp));
                     const float angle = sampler_next(L.smp) * 2 * 3.14159265358979323846264338327950288f;
-                    const float dx = r * cosf(angle), dy = r * sinf(angle);
+                    float sn, cs;
+                    sincosf(angle, &sn, &cs);
+                    const float dx = r * cs, dy = r * sn;
                     const vec3 pd = normalize(w + dx * u + dy * v);
                     i++;
                     if (dot(pd, nrm) <= 0) continue;
