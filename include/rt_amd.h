@@ -67,7 +67,8 @@ typedef struct rt_stats {
     uint64_t nodePairSteps, triangleTests; /* filled only by rt_render with RT_RENDER_COUNT_WORK */
     uint64_t pixels;
     uint64_t stackOverflows; /* must be 0 */
-    uint64_t reserved;
+    uint64_t referenceTreeQueries; /* queries of the last wavefront frame that were traced again in the caller's tree
+                                      because the query tree's result could not be proven equal (see RT_RENDER_REFERENCE_TREE) */
 } rt_stats;
 
 enum {

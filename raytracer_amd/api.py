@@ -53,14 +53,14 @@ class Region(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("primaryRays", "shadowRays", "secondaryRays", "nodePairSteps", "triangleTests",
-                                          "pixels", "stackOverflows", "reserved")]
+                                          "pixels", "stackOverflows", "referenceTreeQueries")]
 
     @property
     def rays(self):
         return self.primaryRays + self.shadowRays + self.secondaryRays
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 class RtError(RuntimeError):

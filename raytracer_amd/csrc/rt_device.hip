@@ -68,6 +68,7 @@ struct rt_scene {
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     uint32_t queryStepBudget = 24;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
     std::vector<int> lightTypes;
+    std::vector<uint32_t> fallSlots; // d_roundCounts entries that count the last frame's fall-back queries
 };
 
 #define RT_HIP(call)                                                                               \
@@ -1908,6 +1909,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         return RT_ERR_LIMIT;
     }
     RT_HIP(hipMemsetAsync(scene->d_roundCounts, 0, countWords * sizeof(uint32_t), st));
+    scene->fallSlots.clear();
     WaveParams P;
     P.S = scene->view;
     P.cam = *camera;
@@ -2000,6 +2002,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             return;
         }
         uint32_t* longCount = scene->d_roundCounts + nextFetch++;
+        if (useQuery) scene->fallSlots.push_back(nextFetch);
         uint32_t* fallCount = scene->d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
         T.runLo = scene->laneModeAbove;
@@ -2105,7 +2108,13 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
         RT_HIP(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
         stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
-        stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->reserved = 0;
+        stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;
+        if (scene->lastWasWavefront && !scene->fallSlots.empty()) {
+            const uint32_t lo = scene->fallSlots.front(), hi = scene->fallSlots.back();
+            std::vector<uint32_t> c(hi - lo + 1);
+            RT_HIP(hipMemcpy(c.data(), scene->d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t slot : scene->fallSlots) stats->referenceTreeQueries += c[slot - lo];
+        }
         if (h[S_OVERFLOW]) {
             rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
             return RT_ERR_LIMIT;

@@ -312,6 +312,52 @@ def test_query_tree_changes_nothing(name, W, H, n):
            (b["stats"].primaryRays, b["stats"].shadowRays, b["stats"].secondaryRays)
 
 
+@pytest.mark.parametrize("name", ["cornell", "teapot", "knot", "cube"])
+def test_query_tree_from_awkward_viewpoints(name):
+    """The same comparison from cameras that make the proof work for its living: inside the model, grazing along walls,
+    looking straight down an axis (direction components exactly zero), far away; with glossy rays in all directions."""
+    g, _, _ = scene_pair(name)
+    W, H = 256, 144
+    cams = [dict(dist=0.05), dict(dist=0.6, rot_deg=(0.0, 0.0, 0.0)), dict(dist=1.2, rot_deg=(90.0, 0.0, 0.0)),
+            dict(dist=0.9, rot_deg=(0.0, 90.0, 0.0), look_at=(0.0, 0.3, 0.0)), dict(dist=25.0, rot_deg=(-35.0, 200.0, 0.0))]
+    again = total = 0
+    for k, cam in enumerate(cams):
+        fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2 + (k % 2), numShadowSamples=2)
+        cg, _ = both_cameras(W, H, **cam)
+        a = g.render_image(cg, fg, W, H, start_depth=3)
+        b = g.render_image(cg, fg, W, H, start_depth=3, flags=api.RT_RENDER_REFERENCE_TREE)
+        assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["t"].view(np.uint32), b["t"].view(np.uint32)), (name, cam)
+        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32)), (name, cam)
+        assert (a["stats"].shadowRays, a["stats"].secondaryRays) == (b["stats"].shadowRays, b["stats"].secondaryRays), (name, cam)
+        again += a["stats"].referenceTreeQueries
+        total += a["stats"].rays
+        assert b["stats"].referenceTreeQueries == 0
+    print(f"{name}: {again} of {total} queries were traced again in the reference's tree")
+    assert again < 0.2 * total
+
+
+def test_query_tree_ties_go_to_the_reference_tree():
+    """Every triangle twice (a scene merged with itself): each hit is an exact tie, which only the order of the
+    reference's own walk decides, so every hitting query must take the second pass - and the frame must still be the
+    oracle's, with the ids of the copies the reference reports."""
+    sc1 = scenes.dragon_standin(n_u=60, n_v=12)
+    sc = scenes.merge(sc1, sc1)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    W, H = 320, 180
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=2)
+    cg, co = both_cameras(W, H, dist=2.0)
+    a = g.render_image(cg, fg, W, H, start_depth=3)
+    b = g.render_image(cg, fg, W, H, start_depth=3, flags=api.RT_RENDER_REFERENCE_TREE)
+    ro = o.render(co, fo, W, H, start_depth=3)
+    compare_frames(a, ro, "doubled knot, query tree")
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    hits = np.count_nonzero(a["prim"] != api.NO_HIT)
+    print("doubled knot:", a["stats"].referenceTreeQueries, "queries traced again;", hits, "primary hits")
+    assert hits > 1000 and a["stats"].referenceTreeQueries >= hits
+    assert np.count_nonzero(a["prim"][a["prim"] != api.NO_HIT] >= len(sc1["prims"])) > 0  # ids of second copies do appear
+
+
 def test_slab_division_is_exact():
     """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
     total = 0
