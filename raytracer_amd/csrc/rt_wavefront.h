@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
         const int e = T.lq - 1 - j;
         const uint32_t ref = lq[e], key = QUERY ? 1u : lq[Lay::kLeafQ + e];
         const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
-        float tl = T.bestT;
+        float tl = T.cullT; // the closest hit any lane of the group holds: nothing beyond it can win (equal distances stay in)
         uint32_t tril = kNoHit;
         leaf_test<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
         if (tril != kNoHit) {
