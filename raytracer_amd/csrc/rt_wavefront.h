@@ -162,6 +162,29 @@ __device__ __forceinline__ uint32_t block_fetch(uint32_t* counter, const bool ne
     return need ? pos : 0xffffffffu;
 }
 
+// block_fetch on two counters with one trip to them.  s_n: 8 words, s_base: 2 words.
+__device__ __forceinline__ void block_fetch2(uint32_t* counterA, const bool needA, uint32_t* counterB, const bool needB, const int lane,
+                                             uint32_t* s_n, uint32_t* s_base, uint32_t& posA, uint32_t& posB)
+{
+    const unsigned long long maskA = __ballot(needA), maskB = __ballot(needB);
+    const int wv = threadIdx.x >> 6;
+    if (lane == 0) s_n[wv] = (uint32_t)__popcll(maskA), s_n[4 + wv] = (uint32_t)__popcll(maskB);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nA = s_n[0] + s_n[1] + s_n[2] + s_n[3], nB = s_n[4] + s_n[5] + s_n[6] + s_n[7];
+        uint32_t bA = 0, bB = 0;
+        if (nA) bA = atomicAdd(counterA, nA);
+        if (nB) bB = atomicAdd(counterB, nB);
+        s_base[0] = bA, s_base[1] = bB;
+    }
+    __syncthreads();
+    uint32_t pA = s_base[0] + (uint32_t)__popcll(maskA & ((1ull << lane) - 1ull));
+    uint32_t pB = s_base[1] + (uint32_t)__popcll(maskB & ((1ull << lane) - 1ull));
+    for (int k = 0; k < wv; k++) pA += s_n[k], pB += s_n[4 + k];
+    __syncthreads();
+    posA = needA ? pA : 0xffffffffu, posB = needB ? pB : 0xffffffffu;
+}
+
 __device__ __forceinline__ void flush_counters(unsigned long long* stats, const int lane, const uint32_t cPrimary, const uint32_t cShadow,
                                                const uint32_t cSecondary, const TraceCounters& tc, const uint32_t cPixels, const uint32_t cDrop)
 {
@@ -596,6 +619,32 @@ __device__ __forceinline__ uint32_t reserve_slots(uint32_t* count, const uint32_
     return (n != 0 && first + n <= cap) ? first : 0xffffffffu;
 }
 
+// The same for three queues at once.  A wave waits for an atomic's answer with all its lanes, and counters that every
+// wave of a launch updates answer slowly: the three updates are issued together and waited for once.
+__device__ __forceinline__ void reserve_slots3(uint32_t* c0, const uint32_t cap0, const uint32_t n0, uint32_t* c1, const uint32_t cap1,
+                                               const uint32_t n1, uint32_t* c2, const uint32_t cap2, const uint32_t n2, const int lane,
+                                               uint32_t& s0, uint32_t& s1, uint32_t& s2)
+{
+    uint32_t i0 = n0, i1 = n1, i2 = n2; // inclusive prefix sums over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o0 = __shfl_up(i0, off), o1 = __shfl_up(i1, off), o2 = __shfl_up(i2, off);
+        if (lane >= off) i0 += o0, i1 += o1, i2 += o2;
+    }
+    const uint32_t t0 = __shfl(i0, 63), t1 = __shfl(i1, 63), t2 = __shfl(i2, 63);
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if (lane == 63) {
+        if (t0) b0 = atomicAdd(c0, t0);
+        if (t1) b1 = atomicAdd(c1, t1);
+        if (t2) b2 = atomicAdd(c2, t2);
+    }
+    b0 = __shfl(b0, 63), b1 = __shfl(b1, 63), b2 = __shfl(b2, 63);
+    const uint32_t f0 = b0 + i0 - n0, f1 = b1 + i1 - n1, f2 = b2 + i2 - n2;
+    s0 = (n0 != 0 && f0 + n0 <= cap0) ? f0 : 0xffffffffu;
+    s1 = (n1 != 0 && f1 + n1 <= cap1) ? f1 : 0xffffffffu;
+    s2 = (n2 != 0 && f2 + n2 <= cap2) ? f2 : 0xffffffffu;
+}
+
 // One sample of renderRayGlossyComponent's loop (src/extra.cpp:489-505): sampleDisk (src/extra.cpp:443-450)
 // draws twice from `smp`; false when the perturbed direction points into the surface.
 __device__ __forceinline__ bool glossy_sample(uint32_t& smp, const float radius, const vec3 w, const vec3 u, const vec3 v, const vec3 nrm, vec3& pd)
@@ -766,10 +815,26 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             default: L.state = PS_DONE; break;
             }
         }
-        // ---- append the tasks produced in this pass (wave-aggregated) ----
+        // ---- queue slots for everything this pass produced (a lane asks for one kind): one trip to the counters ----
+        uint32_t shadeSlot = 0xffffffffu, leafSlot = 0xffffffffu, raySlot = 0xffffffffu;
+        if (__ballot(wantShade || wantLeaf || wantBatch || wantConsume) != 0ull) {
+            const uint32_t N = F.numGlossySamples;
+            reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? N : 0u), P.qCount + 1, P.leafCap,
+                           wantLeaf ? 1u : (wantConsume ? N * N : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane,
+                           shadeSlot, leafSlot, raySlot);
+        }
+        // ---- append the tasks produced in this pass ----
         if (__ballot(wantShade) != 0ull) {
             const bool pushFrame = wantShade && openLoop;
-            if (!queue_append(P.shadeQ, P.qCount + 0, P.shadeCap, wantShade, st, lane)) cDrop++;
+            if (wantShade) {
+                if (shadeSlot != 0xffffffffu) {
+                    const float4* src = reinterpret_cast<const float4*>(&st);
+                    float4* dst = reinterpret_cast<float4*>(P.shadeQ + shadeSlot);
+                    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                } else {
+                    cDrop++;
+                }
+            }
             // lanes that open a glossy loop need frame storage; allocate for those that have none yet
             if (__ballot(pushFrame && frames == nullptr) != 0ull) allocFrames(pushFrame && frames == nullptr);
             if (pushFrame) {
@@ -784,15 +849,21 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 L.state = PS_GLOSSY;
             }
         }
-        if (__ballot(wantLeaf) != 0ull) {
-            if (!queue_append(P.leafQ, P.qCount + 1, P.leafCap, wantLeaf, lt, lane)) cDrop++;
+        if (wantLeaf) {
+            if (leafSlot != 0xffffffffu) {
+                const float4* src = reinterpret_cast<const float4*>(&lt);
+                float4* dst = reinterpret_cast<float4*>(P.leafQ + leafSlot);
+                dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
+            } else {
+                cDrop++;
+            }
         }
         // ---- batched glossy loop: the loop's children are the last rays that can spawn anything, and each of
         // them either consumes no further draws or exactly 2N (its own loop, whose children are deferred).  Child
         // i therefore starts at one of i+1 known sampler offsets: trace a candidate for each, pick afterwards.
         if (__ballot(wantBatch) != 0ull) {
             const uint32_t N = F.numGlossySamples;
-            const uint32_t base = reserve_slots(P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane);
+            const uint32_t base = raySlot;
             if (wantBatch) {
                 if (base == 0xffffffffu) {
                     cDrop++;
@@ -827,8 +898,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         if (__ballot(wantConsume) != 0ull) {
             // the traced candidates are back: walk the loop in the reference's order
             const uint32_t N = F.numGlossySamples;
-            const uint32_t shadeBase = reserve_slots(P.qCount + 0, P.shadeCap, wantConsume ? N : 0u, lane);
-            const uint32_t leafBase = reserve_slots(P.qCount + 1, P.leafCap, wantConsume ? N * N : 0u, lane);
+            const uint32_t shadeBase = shadeSlot, leafBase = leafSlot;
             if (wantConsume) {
                 const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * kFrameDwords);
                 const float4 f0 = fq[0], f3 = fq[3], f4 = fq[4];
@@ -958,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
 __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_n[4], s_base;
+    __shared__ uint32_t s_n[8], s_base[2];
     const int lane = threadIdx.x & 63;
     const uint32_t total = *P.activeInCount;
     uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
@@ -988,9 +1058,9 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
         advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
         const bool active = (L.state == PS_TRACE);
-        const uint32_t pos = block_fetch(P.activeOutCount, active, lane, s_n, &s_base);
-        const bool single = active && L.nRays <= 1;
-        const uint32_t rpos = block_fetch(P.rayCountOut, single, lane, s_n, &s_base); // a batch reserved its rays when it was emitted
+        const bool single = active && L.nRays <= 1; // a batch reserved its rays when it was emitted
+        uint32_t pos, rpos;
+        block_fetch2(P.activeOutCount, active, P.rayCountOut, single, lane, s_n, s_base, pos, rpos);
         if (single) {
             L.nRays = 1;
             L.rayBase = rpos;
