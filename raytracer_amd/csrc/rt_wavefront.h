@@ -619,11 +619,13 @@ __device__ __forceinline__ uint32_t reserve_slots(uint32_t* count, const uint32_
     return (n != 0 && first + n <= cap) ? first : 0xffffffffu;
 }
 
-// The same for three queues at once.  A wave waits for an atomic's answer with all its lanes, and counters that every
-// wave of a launch updates answer slowly: the three updates are issued together and waited for once.
+// The same for three queues at once and for a whole workgroup: every thread of the workgroup must call it.  Counters
+// that every wave of a launch updates answer one update at a time (about 9 ns each: a thousand waves asking together
+// wait 9 us), and a wave waits for the answer with all its lanes - so the workgroup's requests are summed in LDS, one
+// thread issues the three updates together, and they are waited for once.  s_n: 12 words, s_base: 3 words.
 __device__ __forceinline__ void reserve_slots3(uint32_t* c0, const uint32_t cap0, const uint32_t n0, uint32_t* c1, const uint32_t cap1,
                                                const uint32_t n1, uint32_t* c2, const uint32_t cap2, const uint32_t n2, const int lane,
-                                               uint32_t& s0, uint32_t& s1, uint32_t& s2)
+                                               uint32_t* s_n, uint32_t* s_base, uint32_t& s0, uint32_t& s1, uint32_t& s2)
 {
     uint32_t i0 = n0, i1 = n1, i2 = n2; // inclusive prefix sums over the wave
 #pragma unroll
@@ -631,15 +633,21 @@ __device__ __forceinline__ void reserve_slots3(uint32_t* c0, const uint32_t cap0
         const uint32_t o0 = __shfl_up(i0, off), o1 = __shfl_up(i1, off), o2 = __shfl_up(i2, off);
         if (lane >= off) i0 += o0, i1 += o1, i2 += o2;
     }
-    const uint32_t t0 = __shfl(i0, 63), t1 = __shfl(i1, 63), t2 = __shfl(i2, 63);
-    uint32_t b0 = 0, b1 = 0, b2 = 0;
-    if (lane == 63) {
+    const int wv = threadIdx.x >> 6;
+    if (lane == 63) s_n[wv] = i0, s_n[4 + wv] = i1, s_n[8 + wv] = i2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t0 = s_n[0] + s_n[1] + s_n[2] + s_n[3], t1 = s_n[4] + s_n[5] + s_n[6] + s_n[7], t2 = s_n[8] + s_n[9] + s_n[10] + s_n[11];
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
         if (t0) b0 = atomicAdd(c0, t0);
         if (t1) b1 = atomicAdd(c1, t1);
         if (t2) b2 = atomicAdd(c2, t2);
+        s_base[0] = b0, s_base[1] = b1, s_base[2] = b2;
     }
-    b0 = __shfl(b0, 63), b1 = __shfl(b1, 63), b2 = __shfl(b2, 63);
-    const uint32_t f0 = b0 + i0 - n0, f1 = b1 + i1 - n1, f2 = b2 + i2 - n2;
+    __syncthreads();
+    uint32_t f0 = s_base[0] + i0 - n0, f1 = s_base[1] + i1 - n1, f2 = s_base[2] + i2 - n2;
+    for (int k = 0; k < wv; k++) f0 += s_n[k], f1 += s_n[4 + k], f2 += s_n[8 + k];
+    __syncthreads();
     s0 = (n0 != 0 && f0 + n0 <= cap0) ? f0 : 0xffffffffu;
     s1 = (n1 != 0 && f1 + n1 <= cap1) ? f1 : 0xffffffffu;
     s2 = (n2 != 0 && f2 + n2 <= cap2) ? f2 : 0xffffffffu;
@@ -677,11 +685,12 @@ __device__ __forceinline__ void store_leaf_task(LeafTask* q, const uint32_t pixe
 constexpr uint32_t kHolePixel = 0xffffffffu; // a reserved but unused ShadeTask slot
 
 // Advances every lane from "its ray has been traced" (PS_HIT) to its next ray (PS_TRACE) or the end
-// of its pixel (PS_DONE), appending the shade / leaf tasks met on the way.  Wave-convergent.
+// of its pixel (PS_DONE), appending the shade / leaf tasks met on the way.  Every thread of the workgroup must call it
+// (the passes are workgroup-convergent: queue slots are reserved per workgroup).  s_n: 12 words, s_base: 3 words of LDS.
 // frames: this lane's frame storage in HBM (null while the lane has none: lanes allocate lazily).
 template <typename AllocFn>
 __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, float*& frames, AllocFn&& allocFrames, const int lane,
-                                              uint32_t& cPrimary, uint32_t& cSecondary, uint32_t& cDrop)
+                                              uint32_t& cPrimary, uint32_t& cSecondary, uint32_t& cDrop, uint32_t* s_n, uint32_t* s_base)
 {
     const SceneView& S = P.S;
     const rt_features& F = P.F;
@@ -817,11 +826,11 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         }
         // ---- queue slots for everything this pass produced (a lane asks for one kind): one trip to the counters ----
         uint32_t shadeSlot = 0xffffffffu, leafSlot = 0xffffffffu, raySlot = 0xffffffffu;
-        if (__ballot(wantShade || wantLeaf || wantBatch || wantConsume) != 0ull) {
+        {
             const uint32_t N = F.numGlossySamples;
             reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? N : 0u), P.qCount + 1, P.leafCap,
-                           wantLeaf ? 1u : (wantConsume ? N * N : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane,
-                           shadeSlot, leafSlot, raySlot);
+                           wantLeaf ? 1u : (wantConsume ? N * N : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane, s_n,
+                           s_base, shadeSlot, leafSlot, raySlot);
         }
         // ---- append the tasks produced in this pass ----
         if (__ballot(wantShade) != 0ull) {
@@ -953,7 +962,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 L.state = PS_POP;
             }
         }
-    } while (__ballot(L.state > PS_TRACE) != 0ull);
+    } while (__syncthreads_or(L.state > PS_TRACE));
 }
 
 // Round 0: camera rays.  Most pixels of a frame look past the scene: only a pixel whose ray enters the root
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
 __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_n[8], s_base[2];
+    __shared__ uint32_t s_n[12], s_base[3];
     const int lane = threadIdx.x & 63;
     const uint32_t total = *P.activeInCount;
     uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
@@ -1056,7 +1065,7 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
             }
         }
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
-        advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop);
+        advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
         const bool active = (L.state == PS_TRACE);
         const bool single = active && L.nRays <= 1; // a batch reserved its rays when it was emitted
         uint32_t pos, rpos;
