@@ -427,6 +427,8 @@ template <bool CULL, bool COUNT, int STACK, bool QUERY = false>
 __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const TraceParams P)
 {
     __shared__ uint32_t s_stack[2 * STACK * kBlock]; // per lane: STACK node references, then their entry distances
+    __shared__ uint32_t s_long[(kBlock / 64) * 128]; // per wave: rays to hand over, not yet on the list
+    uint32_t nLong = 0;
     uint32_t* const stack = s_stack + threadIdx.x;
     const SceneView& S = P.S;
     const int lane = threadIdx.x & 63;
@@ -505,12 +507,28 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
         if (budget != 0) { // the few long rays would hold the whole stage at one-lane speed: hand them over
             steps += kStepsPerCheck;
             const bool giveUp = has && steps > budget;
-            const uint32_t pos = wave_fetch(P.longCount, giveUp, lane);
-            if (giveUp) {
-                P.longList[pos] = idx;
-                has = false;
+            const unsigned long long gm = __ballot(giveUp);
+            if (gm != 0ull) { // collected per wave in LDS, appended to the list 64 or more at a time (the list's counter is one address)
+                if (giveUp) {
+                    s_long[(threadIdx.x >> 6) * 128 + nLong + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = idx;
+                    has = false;
+                }
+                nLong += (uint32_t)__popcll(gm);
+                if (nLong >= 64u) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.longCount, nLong);
+                    base = __shfl(base, 0);
+                    for (uint32_t k = lane; k < nLong; k += 64u) P.longList[base + k] = s_long[(threadIdx.x >> 6) * 128 + k];
+                    nLong = 0;
+                }
             }
         }
+    }
+    if (nLong != 0u) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(P.longCount, nLong);
+        base = __shfl(base, 0);
+        for (uint32_t k = lane; k < nLong; k += 64u) P.longList[base + k] = s_long[(threadIdx.x >> 6) * 128 + k];
     }
     if (COUNT || __ballot(tc.overflow != 0) != 0ull) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
 }
