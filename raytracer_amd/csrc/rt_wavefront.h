@@ -987,66 +987,86 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
 // box (or that has further pixel samples to take) gets a recursion state and a ray to trace.
 __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_n[4], s_base;
+    constexpr int kPer = 4; // pixels per thread and trip: the active list's counter is updated once per 1024 pixels
+    __shared__ uint32_t s_n[4 * kPer], s_base;
     const rt_features& F = P.F;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t nPixelRays = pixel_ray_count(F);
     uint32_t cPrimary = 0, cPixels = 0, cDrop = 0;
     TraceCounters tc { 0, 0, 0 };
-    for (uint32_t base = blockIdx.x * kBlock; base < P.nWork; base += gridDim.x * kBlock) { // block-uniform trip count
-        const uint32_t w = base + threadIdx.x;
-        PathLane L;
-        L.state = PS_DONE;
-        L.nRays = 1, L.rayBase = 0;
-        if (w < P.nWork) {
-            const uint32_t tile = w >> 6, l = w & 63;
-            const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
-            const uint32_t blk = m / P.stripeTileRows, r = m - blk * P.stripeTileRows;
-            const uint32_t ty = (blk * P.world + P.rank) * P.stripeTileRows + r;
-            const uint32_t px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
-            if (px < (uint32_t)P.W && py < (uint32_t)P.H) {
+    // pixel of work item w and its first ray; false outside the frame
+    auto pixel_setup = [&](const uint32_t w, PathLane& L) -> bool {
+        if (w >= P.nWork) return false;
+        const uint32_t tile = w >> 6, l = w & 63;
+        const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
+        const uint32_t blk = m / P.stripeTileRows, r = m - blk * P.stripeTileRows;
+        const uint32_t ty = (blk * P.world + P.rank) * P.stripeTileRows + r;
+        const uint32_t px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
+        if (!(px < (uint32_t)P.W && py < (uint32_t)P.H)) return false;
+        L.pixel = (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px; // Screen::indexAt (src/screen.cpp:119-122)
+        L.seed = static_cast<uint32_t>(P.H * (int)px + (int)py);      // src/render.cpp:38
+        L.smp = L.seed;
+        L.pxy = px | (py << 16);
+        for (uint32_t k = 0; k < (F.numPixelSamples > 1 ? 2 * nPixelRays : 0u); k++) (void)sampler_next(L.smp);
+        make_pixel_ray(P, L, 0, nPixelRays);
+        return true;
+    };
+    for (uint32_t base = blockIdx.x * (kBlock * kPer); base < P.nWork; base += gridDim.x * (kBlock * kPer)) { // block-uniform trip count
+        unsigned long long mask[kPer];
+        bool live[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            PathLane L;
+            L.nRays = 1, L.rayBase = 0;
+            live[k] = false;
+            if (pixel_setup(base + k * kBlock + threadIdx.x, L)) {
                 cPixels++;
-                L.pixel = (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px; // Screen::indexAt (src/screen.cpp:119-122)
-                L.seed = static_cast<uint32_t>(P.H * (int)px + (int)py);      // src/render.cpp:38
-                L.smp = L.seed;
-                L.pxy = px | (py << 16);
-                for (uint32_t k = 0; k < (F.numPixelSamples > 1 ? 2 * nPixelRays : 0u); k++) (void)sampler_next(L.smp);
+                cPrimary++;
+                const uint32_t px = L.pxy & 0xffffu, py = L.pxy >> 16;
                 if (P.primId) P.primId[py * P.W + px] = kNoHit;
                 if (P.primT) P.primT[py * P.W + px] = FLT_MAX;
-                make_pixel_ray(P, L, 0, nPixelRays);
-                cPrimary++;
-                bool live = nPixelRays > 1 || !F.enableAccelStructure;
-                if (!live) { // the root test every query starts with (src/bvh.cpp:264-268)
+                live[k] = nPixelRays > 1 || !F.enableAccelStructure;
+                if (!live[k]) { // the root test every query starts with (src/bvh.cpp:264-268)
                     const RaySlabs R = make_slabs(P.S, L.to, L.td);
                     float tr;
                     bool outside;
-                    live = box_test_any(P.S.rootLo[0], P.S.rootLo[1], P.S.rootLo[2], P.S.rootHi[0], P.S.rootHi[1], P.S.rootHi[2], R, FLT_MAX, tr,
-                                        outside);
+                    live[k] = box_test_any(P.S.rootLo[0], P.S.rootLo[1], P.S.rootLo[2], P.S.rootHi[0], P.S.rootHi[1], P.S.rootHi[2], R, FLT_MAX,
+                                           tr, outside);
                 }
-                if (live) L.state = PS_TRACE;
             }
+            mask[k] = __ballot(live[k]);
+            if (lane == 0) s_n[k * 4 + wv] = (uint32_t)__popcll(mask[k]);
         }
-        // one counter update per workgroup: state slot = ray slot = position in the first active list
-        const bool active = (L.state == PS_TRACE);
-        const unsigned long long mask = __ballot(active);
-        const int wv = threadIdx.x >> 6;
-        if (lane == 0) s_n[wv] = (uint32_t)__popcll(mask);
+        // one counter update per workgroup and trip: state slot = ray slot = position in the first active list
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t n = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+            uint32_t n = 0;
+            for (int k = 0; k < 4 * kPer; k++) n += s_n[k];
             s_base = n ? atomicAdd(P.activeOutCount, n) : 0u; // also the number of rays: the host reads round 0's from here
         }
         __syncthreads();
-        uint32_t pos = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        for (int k = 0; k < wv; k++) pos += s_n[k];
+        uint32_t run = s_base;
+        uint32_t pos[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            for (int w = 0; w < 4; w++) {
+                if (w == wv) pos[k] = run + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull));
+                run += s_n[k * 4 + w];
+            }
         __syncthreads();
-        if (active) {
-            L.rayBase = pos;
-            if (pos < P.rayCap) store_ray(P.pathRays + pos, L.to, L.td, FLT_MAX, 0u);
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            if (!live[k]) continue;
+            PathLane L;
+            L.nRays = 1;
+            (void)pixel_setup(base + k * kBlock + threadIdx.x, L);
+            L.state = PS_TRACE;
+            L.rayBase = pos[k];
+            if (pos[k] < P.rayCap) store_ray(P.pathRays + pos[k], L.to, L.td, FLT_MAX, 0u);
             else cDrop++;
-            store_header(P.states + (size_t)pos * kStateDwords, L);
-            P.activeOut[pos] = pos;
-            P.activeRayOut[pos] = pos;
+            store_header(P.states + (size_t)pos[k] * kStateDwords, L);
+            P.activeOut[pos[k]] = pos[k];
+            P.activeRayOut[pos[k]] = pos[k];
         }
     }
     flush_counters(P.stats, lane, cPrimary, 0, 0, tc, cPixels, cDrop);
@@ -1433,43 +1453,54 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
 // Deferred rays at the recursion limit: a hit becomes a ShadeTask.
 __global__ __launch_bounds__(kBlock) void leaf_logic_kernel(const WaveParams P)
 {
-    __shared__ uint32_t s_n[4], s_base;
-    const int lane = threadIdx.x & 63;
+    constexpr int kPer = 4; // tasks per thread and trip: the shade queue's counter is updated once per 1024 tasks
+    __shared__ uint32_t s_n[4 * kPer], s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t total = min(P.qCount[1], P.leafCap);
     TraceCounters tc { 0, 0, 0 };
     uint32_t cDrop = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) { // block-uniform trip count
-        const uint32_t i = base + threadIdx.x;
-        ShadeTask st;
-        bool want = false;
-        if (i < total) {
-            const HitRec hr = P.hits[i];
-            if (hr.tri != kNoHit) {
-                const float4* q = reinterpret_cast<const float4*>(P.leafQ + i);
-                const float4 a = q[0], b = q[1], c = q[2];
-                const vec3 o = make3(a.x, a.y, a.z), d = make3(b.x, b.y, b.z), W = make3(c.x, c.y, c.z);
-                Hit h;
-                fill_hit(P.S, P.F, hr.tri, o, d, hr.t, h);
-                const vec3 p = o + hr.t * d;
-                st.pixel = __float_as_uint(b.w);
-                st.matInfo = h.mesh | (h.isSphere ? 0x80000000u : 0u);
-                st.smp = 0, st.tri = hr.tri;
-                st.W[0] = W.x, st.W[1] = W.y, st.W[2] = W.z;
-                st.px = p.x, st.py = p.y, st.pz = p.z;
-                st.dx = d.x, st.dy = d.y, st.dz = d.z;
-                st.nx = h.normal.x, st.ny = h.normal.y, st.nz = h.normal.z;
-                want = true;
-            }
+    for (uint32_t base = blockIdx.x * (kBlock * kPer); base < total; base += gridDim.x * (kBlock * kPer)) { // block-uniform trip count
+        HitRec hr[kPer];
+        unsigned long long mask[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const uint32_t i = base + k * kBlock + threadIdx.x;
+            hr[k] = HitRec { 0.0f, kNoHit };
+            if (i < total) hr[k] = P.hits[i];
+            mask[k] = __ballot(hr[k].tri != kNoHit);
+            if (lane == 0) s_n[k * 4 + wv] = (uint32_t)__popcll(mask[k]);
         }
-        const uint32_t slot = block_fetch(P.qCount + 0, want, lane, s_n, &s_base);
-        if (want) {
-            if (slot < P.shadeCap) {
-                const float4* src = reinterpret_cast<const float4*>(&st);
-                float4* dst = reinterpret_cast<float4*>(P.shadeQ + slot);
-                dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
-            } else {
-                cDrop++;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t n = 0;
+            for (int k = 0; k < 4 * kPer; k++) n += s_n[k];
+            s_base = n ? atomicAdd(P.qCount + 0, n) : 0u;
+        }
+        __syncthreads();
+        uint32_t run = s_base;
+        uint32_t slot[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            for (int w = 0; w < 4; w++) {
+                if (w == wv) slot[k] = run + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull));
+                run += s_n[k * 4 + w];
             }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            if (hr[k].tri == kNoHit) continue;
+            if (slot[k] >= P.shadeCap) {
+                cDrop++;
+                continue;
+            }
+            const uint32_t i = base + k * kBlock + threadIdx.x;
+            const float4* q = reinterpret_cast<const float4*>(P.leafQ + i);
+            const float4 a = q[0], b = q[1], c = q[2];
+            const vec3 o = make3(a.x, a.y, a.z), d = make3(b.x, b.y, b.z), W = make3(c.x, c.y, c.z);
+            Hit h;
+            fill_hit(P.S, P.F, hr[k].tri, o, d, hr[k].t, h);
+            store_shade_task(P.shadeQ + slot[k], __float_as_uint(b.w), h.mesh | (h.isSphere ? 0x80000000u : 0u), 0u, hr[k].tri, W,
+                             o + hr[k].t * d, d, h.normal);
         }
     }
     flush_counters(P.stats, lane, 0, 0, 0, tc, 0, cDrop);
