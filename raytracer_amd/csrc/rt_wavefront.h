@@ -1291,7 +1291,9 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
         const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
         float tl = T.cullT; // the closest hit any lane of the group holds: nothing beyond it can win (equal distances stay in)
         uint32_t tril = kNoHit;
-        leaf_test<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
+        // query-tree launches: one triangle in flight at a time keeps the kernel free of register spills at 4 waves per SIMD
+        if (QUERY) leaf_test_narrow<COUNT, true>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
+        else leaf_test<COUNT, false>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
         if (tril != kNoHit) {
             if (QUERY) { // the walk's order means nothing here: equal distances are only noted
                 if (tl == T.bestT && T.bestTri != kNoHit) T.tieT = tl;
