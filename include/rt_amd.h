@@ -190,6 +190,15 @@ int rt_intersect(rt_scene* scene, const rt_features* features, float* rays, uint
  * the reference's `(bound - origin) / direction` over ~4M pseudo-random and edge-case operand pairs. */
 int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked);
 
+/* Diagnostic with no counterpart in the reference, host only (no GPU needed): flattens the tree as rt_scene_create
+ * does, builds the library's query tree (see RT_RENDER_REFERENCE_TREE) and checks it - every triangle of the
+ * reference's leaves in exactly one query-tree leaf, every child box inside the box stored for it and around its
+ * triangles, both forms of the tree holding the same leaves, and each triangle's record naming its reference leaf's
+ * box and route.  info (8 words): usable (0/1), triangles, binary pairs, binary depth, 4-wide nodes, 4-wide depth,
+ * reference pairs, reference depth.  Returns RT_OK when the checks hold (usable = 0 when the reference's boxes are not
+ * nested or too few triangles: queries then walk the caller's tree only). */
+int rt_selftest_query_tree(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, uint32_t info[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -559,6 +559,126 @@ const void* rt_bvh_nodes(const rt_bvh* b) { return b ? b->nodes.data() : nullptr
 const void* rt_bvh_primitives(const rt_bvh* b) { return b ? b->prims.data() : nullptr; }
 const uint32_t* rt_bvh_primitive_ids(const rt_bvh* b) { return b ? b->primIds.data() : nullptr; }
 
+int rt_selftest_query_tree(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, uint32_t info[8])
+{
+    if (!nodes || !info) {
+        set_error("rt_selftest_query_tree: null argument");
+        return RT_ERR_INVALID;
+    }
+    FlatScene flat;
+    const char* err = "";
+    const int rc = flatten(static_cast<const RefNode*>(nodes), nNodes, static_cast<const RefPrimitive*>(prims), nPrims, nullptr, nMaterials,
+                           flat, &err);
+    if (rc != RT_OK) {
+        set_error("%s", err);
+        return rc;
+    }
+    QueryTree qt;
+    build_query_tree(flat, qt);
+    const uint32_t n = uint32_t(flat.triPlane.size());
+    info[0] = qt.usable ? 1u : 0u, info[1] = n, info[2] = uint32_t(qt.pairs.size()), info[3] = qt.pairDepth;
+    info[4] = uint32_t(qt.nodes.size()), info[5] = qt.maxDepth, info[6] = uint32_t(flat.pairs.size()), info[7] = flat.maxDepth;
+    if (!qt.usable) return RT_OK;
+    auto fail = [](const char* what) {
+        set_error("rt_selftest_query_tree: %s", what);
+        return RT_ERR_INVALID;
+    };
+    // the triangle records: a permutation of the reference's, each with its reference leaf's box and route
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const TriCert& c = qt.cert[i];
+        if (c.compact >= n || seen[c.compact]) return fail("triangle records are not a permutation");
+        seen[c.compact] = 1;
+        if (memcmp(&qt.triPlane[i], &flat.triPlane[c.compact], sizeof(TriPlane)) || memcmp(&qt.triEdges[i], &flat.triEdges[c.compact], sizeof(TriEdges)))
+            return fail("triangle data differs from the reference's");
+        // walk the route in the reference's tree: it must end in the leaf that holds the triangle, with this box
+        uint32_t ref = flat.rootRef;
+        const float *lo = flat.rootLo, *hi = flat.rootHi;
+        int top = 31;
+        while (top > 0 && !((c.route >> top) & 1u)) top--;
+        for (int k = top - 1; k >= 0; k--) {
+            if (ref & kLeafBit) return fail("route runs past a leaf");
+            const NodePair& p = flat.pairs[ref];
+            const bool second = (c.route >> k) & 1u;
+            lo = second ? p.lo1 : p.lo0, hi = second ? p.hi1 : p.hi0, ref = second ? p.ref1 : p.ref0;
+        }
+        if (!(ref & kLeafBit)) return fail("route does not end in a leaf");
+        const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+        if (c.compact < first || c.compact >= first + cnt) return fail("route ends in another leaf");
+        if (memcmp(lo, c.leafLo, 12) || memcmp(hi, c.leafHi, 12)) return fail("leaf box differs");
+    }
+    auto triInside = [&](uint32_t t, const float* lo, const float* hi) {
+        const TriEdges& e = qt.triEdges[t];
+        const float v[3][3] = { { e.v0[0], e.v0[1], e.v0[2] }, { e.v1x, e.v1y, e.v1z }, { e.v2[0], e.v2[1], e.v2[2] } };
+        for (int a = 0; a < 3; a++)
+            for (int k = 0; k < 3; k++)
+                if (!(v[a][k] >= lo[k] && v[a][k] <= hi[k])) return false;
+        return true;
+    };
+    // binary form: leaves cover [0, n) once, child boxes nested and around their triangles
+    std::vector<uint8_t> covered(n, 0);
+    std::vector<uint64_t> leavesA, leavesB;
+    struct Item { uint32_t ref; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    auto pushChild = [&](uint32_t ref, const float* lo, const float* hi, const float* plo, const float* phi, bool checkParent) {
+        if (checkParent)
+            for (int k = 0; k < 3; k++)
+                if (!(lo[k] >= plo[k] && hi[k] <= phi[k])) return false;
+        Item it;
+        it.ref = ref;
+        memcpy(it.lo, lo, 12), memcpy(it.hi, hi, 12);
+        stack.push_back(it);
+        return true;
+    };
+    for (int form = 0; form < 2; form++) {
+        std::vector<uint64_t>& leaves = form == 0 ? leavesA : leavesB;
+        stack.clear();
+        Item root;
+        root.ref = form == 0 ? qt.pairRootRef : qt.rootRef;
+        memcpy(root.lo, flat.rootLo, 12), memcpy(root.hi, flat.rootHi, 12);
+        stack.push_back(root);
+        bool isRoot = true;
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.ref & kLeafBit) {
+                const uint32_t first = it.ref & kRefOffsetMask, cnt = (it.ref >> kRefCountShift) & kMaxLeafCount;
+                if (first + cnt > n || cnt == 0) return fail("leaf range out of bounds");
+                for (uint32_t t = first; t < first + cnt; t++) {
+                    if (!triInside(t, it.lo, it.hi)) return fail("triangle outside its leaf box");
+                    if (form == 0) {
+                        if (covered[t]) return fail("triangle in two leaves");
+                        covered[t] = 1;
+                    }
+                }
+                leaves.push_back((uint64_t(first) << 32) | cnt);
+                continue;
+            }
+            if (form == 0) {
+                if (it.ref >= qt.pairs.size()) return fail("pair index out of range");
+                const NodePair& p = qt.pairs[it.ref];
+                if (!pushChild(p.ref0, p.lo0, p.hi0, it.lo, it.hi, !isRoot) || !pushChild(p.ref1, p.lo1, p.hi1, it.lo, it.hi, !isRoot))
+                    return fail("child box outside its parent's");
+            } else {
+                if (it.ref >= qt.nodes.size()) return fail("node index out of range");
+                const Node4& nd = qt.nodes[it.ref];
+                for (int k = 0; k < 4; k++) {
+                    if (nd.ref[k] == kEmptyRef) continue;
+                    const float lo[3] = { nd.lox[k], nd.loy[k], nd.loz[k] }, hi[3] = { nd.hix[k], nd.hiy[k], nd.hiz[k] };
+                    if (!pushChild(nd.ref[k], lo, hi, it.lo, it.hi, !isRoot)) return fail("child box outside its parent's");
+                }
+            }
+            isRoot = false;
+        }
+    }
+    for (uint32_t t = 0; t < n; t++)
+        if (!covered[t]) return fail("triangle in no leaf");
+    std::sort(leavesA.begin(), leavesA.end());
+    std::sort(leavesB.begin(), leavesB.end());
+    if (leavesA != leavesB) return fail("the two forms of the tree hold different leaves");
+    return RT_OK;
+}
+
 int rt_camera_from_trackball(float fovDegrees, float distance, const float lookAt[3], const float rotationDegrees[3],
                              float aspect, rt_camera* out)
 {

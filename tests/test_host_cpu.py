@@ -81,6 +81,44 @@ def test_dragon_standin_is_stable(rt):
     assert (b.num_nodes, b.num_levels, b.num_leaves) == (65536, 16, 32768)
 
 
+@pytest.mark.parametrize("name", ["cube", "cornell", "monkey", "teapot", "knot", "dragon"])
+def test_query_tree_is_a_sound_index_of_the_reference_tree(rt, name):
+    """The library's own traversal tree (host build): every triangle of the reference's leaves in exactly one leaf, boxes
+    nested and around their triangles, the binary and the 4-wide form holding the same leaves, and every triangle's
+    record naming the box and the route of its reference leaf - what the GPU's proof of equality relies on."""
+    from raytracer_amd import scenes
+    if name in ("knot", "dragon"):
+        sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.dragon_standin()
+        prims, mats = sc["prims"], sc["materials"]
+    else:
+        prims, mats, _, _ = O.load_scene_arrays(name)
+    b = rt.Bvh(prims)
+    info = (C.c_uint32 * 8)()
+    rc = rt.lib().rt_selftest_query_tree(b.nodes().ctypes.data_as(C.c_void_p), b.num_nodes, b.primitives().ctypes.data_as(C.c_void_p),
+                                         b.num_primitives, len(mats), info)
+    assert rc == rt.RT_OK, rt.lib().rt_last_error().decode()
+    usable, tris, pairs, pdepth, nodes4, depth4, rpairs, rdepth = list(info)
+    print(name, list(info))
+    assert usable == 1 and tris == len(prims)
+    assert pairs >= tris // 4 and nodes4 < pairs and depth4 <= (pdepth + 1) // 2 + 1
+    if name == "dragon":
+        assert (rpairs, rdepth) == (32767, 16)
+
+
+def test_query_tree_is_not_used_for_unnested_boxes(rt):
+    """A caller's tree whose child boxes stick out of their parents' cannot carry the proof: the library must say so."""
+    prims, mats, _, _ = O.load_scene_arrays("monkey")
+    b = rt.Bvh(prims)
+    nodes = b.nodes().view(np.uint32).reshape(-1, 8).copy()
+    f = nodes.view(np.float32)
+    inner = [i for i in range(2, len(nodes)) if not (nodes[i, 6] >> 31)]
+    f[inner[3], 3:6] += 0.25  # an inner node's upper corner beyond its parent's
+    info = (C.c_uint32 * 8)()
+    rc = rt.lib().rt_selftest_query_tree(nodes.ctypes.data_as(C.c_void_p), len(nodes), b.primitives().ctypes.data_as(C.c_void_p),
+                                         b.num_primitives, len(mats), info)
+    assert rc == rt.RT_OK and info[0] == 0
+
+
 def test_camera_matches_oracle(rt):
     for W, H in ((1920, 1080), (512, 512), (97, 61)):
         got = rt.camera_from_trackball(W, H)
