@@ -358,6 +358,24 @@ def test_query_tree_ties_go_to_the_reference_tree():
     assert np.count_nonzero(a["prim"][a["prim"] != api.NO_HIT] >= len(sc1["prims"])) > 0  # ids of second copies do appear
 
 
+def test_unnested_caller_tree_is_walked_as_given():
+    """A caller's tree whose boxes are not nested cannot carry the query tree's proof: every query walks the tree as given,
+    and the frame is the one RT_RENDER_REFERENCE_TREE gives (here also the oracle's: the enlarged box only adds visits)."""
+    _, o, sc = scene_pair("monkey")
+    bvh = api.Bvh(sc["prims"])
+    nodes = bvh.nodes().view(np.uint32).reshape(-1, 8).copy()
+    inner = [i for i in range(2, len(nodes)) if not (nodes[i, 6] >> 31)]
+    nodes.view(np.float32)[inner[3], 3:6] += 0.25
+    g = api.Scene(nodes, bvh.primitives(), bvh.primitive_ids(), sc["materials"], sc["lights"], sc["spheres"])
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=2)
+    cg, co = both_cameras(320, 180)
+    a = g.render_image(cg, fg, 320, 180, start_depth=3)
+    b = g.render_image(cg, fg, 320, 180, start_depth=3, flags=api.RT_RENDER_REFERENCE_TREE)
+    assert a["stats"].referenceTreeQueries == 0
+    assert np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    compare_frames(a, o.render(co, fo, 320, 180, start_depth=3), "monkey, unnested caller tree")
+
+
 def test_slab_division_is_exact():
     """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
     total = 0
