@@ -475,6 +475,70 @@ def test_headline_config_at_full_size():
     assert np.array_equal(again["rgb"].view(np.uint32), rg["rgb"].view(np.uint32))
 
 
+def _dragon_pair():
+    if "dragon" not in _scene_cache:
+        sc = scenes.dragon_standin()
+        _scene_cache["dragon"] = (api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"]),
+                                  O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"]), sc)
+    return _scene_cache["dragon"]
+
+
+def test_teapot_and_monkey_config_at_full_size():
+    """configs[1]: teapot + monkey in one scene, 1920x1080, Phong + shadows + mirror reflections, 4 bounces."""
+    sc = scenes.merge(scenes.preset("teapot"), scenes.preset("monkey"))
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
+    o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
+    W, H = 1920, 1080
+    fg, fo = both_features()
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    compare_frames(rg, ro, "teapot + monkey 1080p")
+    assert_ray_counts(rg["stats"], ro["stats"], "teapot + monkey 1080p")
+
+
+def test_traversal_stress_config_at_full_size():
+    """configs[2]: dragon stand-in, 1920x1080, primary and shadow rays only."""
+    g, o, _ = _dragon_pair()
+    W, H = 1920, 1080
+    fg, fo = both_features(enableReflections=0)
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=0)
+    ro = o.render(co, fo, W, H, start_depth=0)
+    compare_frames(rg, ro, "dragon stand-in 1080p primary + shadow")
+    assert_ray_counts(rg["stats"], ro["stats"], "dragon stand-in 1080p primary + shadow")
+    assert rg["stats"].secondaryRays == 0
+
+
+@pytest.mark.parametrize("rot_y", [110.0, 245.0])
+def test_camera_sweep_frame_at_4k(rot_y):
+    """configs[4]: one frame of the 3840x2160 camera sweep (glossy x4, 4 bounces, bloom), rendered as the
+    two stripes two ranks would take and as one frame; both against the oracle's frame."""
+    g, o, _ = _dragon_pair()
+    W, H = 3840, 2160
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=4, enableBloomEffect=1)
+    cg, co = both_cameras(W, H, rot_deg=(20.0, rot_y, 0.0))
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    ro["rgb"] = O.bloom(ro["rgb"], fo.bloomFilterSize, fo.bloomFilterThreshold, fo.bloomFilterIntensity)
+    compare_frames(rg, ro, f"dragon stand-in 4K sweep frame, rotation.y {rot_y}")
+    gs, os_ = rg["stats"], ro["stats"]
+    for a, b in zip((gs.primaryRays, gs.shadowRays, gs.secondaryRays), (os_["primary"], os_["shadow"], os_["secondary"])):
+        assert abs(a - b) <= max(1, 1e-4 * b)
+    torch = pytest.importorskip("torch")
+    stream = torch.cuda.current_stream().cuda_stream
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    scratch = torch.empty_like(acc)
+    rays = 0
+    for rank in range(2):
+        g.render_device(cg, fg, W, H, 2, acc.data_ptr(), region=api.Region(16, rank, 2), stream=stream)
+        rays += g.sync(stream).rays
+    assert rays == gs.rays
+    api.bloom_device(acc.data_ptr(), scratch.data_ptr(), W, H, fg.bloomFilterSize, fg.bloomFilterThreshold, fg.bloomFilterIntensity, stream=stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy().view(np.uint32), rg["rgb"].view(np.uint32))
+
+
 def test_cpp_host_interface_renders_the_same_frame(tmp_path):
     """raytracer_amd/host (BVH / Trackball / Screen / renderImage in the reference's shapes) against the Python
     route to the same C ABI and against the oracle, on the example program's procedural scene."""
