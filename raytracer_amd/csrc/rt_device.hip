@@ -2038,6 +2038,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         P.activeRayIn = scene->d_activeRay[(r - 1) & 1], P.activeRayOut = scene->d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
         hipLaunchKernelGGL(path_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     }
+    // what the batched loops left for later: their children's hit records and the grandchildren's rays
+    if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     launch_trace(scene->d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, scene->leafCap, 1);
     hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     for (uint32_t c = 0; c < nChunks; c++) {

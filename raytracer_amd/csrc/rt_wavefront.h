@@ -693,6 +693,19 @@ __device__ __forceinline__ void store_shade_task(ShadeTask* q, const uint32_t pi
     o[2] = make_float4(p.y, p.z, d.x, d.y);
     o[3] = make_float4(d.z, n.x, n.y, n.z);
 }
+// A hit of a batched glossy loop's child as path_logic_kernel leaves it: the ray and where it ended.  shade_expand_kernel
+// turns it into the ShadeTask proper and, with leafSlot != 0xffffffff, draws the child's own glossy loop into the N LeafTask
+// slots from there.
+constexpr uint32_t kRawShade = 0x7fffffffu; // in the matInfo word: no mesh or sphere index reaches it
+__device__ __forceinline__ void store_raw_shade_task(ShadeTask* q, const uint32_t pixel, const uint32_t smp, const uint32_t tri, const vec3 W,
+                                                     const vec3 o, const vec3 d, const float t, const uint32_t leafSlot)
+{
+    float4* out = reinterpret_cast<float4*>(q);
+    out[0] = make_float4(__uint_as_float(pixel), __uint_as_float(kRawShade), __uint_as_float(smp), __uint_as_float(tri));
+    out[1] = make_float4(W.x, W.y, W.z, o.x);
+    out[2] = make_float4(o.y, o.z, d.x, d.y);
+    out[3] = make_float4(d.z, t, __uint_as_float(leafSlot), 0.0f);
+}
 __device__ __forceinline__ void store_leaf_task(LeafTask* q, const uint32_t pixel, const vec3 o, const vec3 d, const float tmax, const vec3 W)
 {
     float4* out = reinterpret_cast<float4*>(q);
@@ -701,7 +714,6 @@ __device__ __forceinline__ void store_leaf_task(LeafTask* q, const uint32_t pixe
     out[2] = make_float4(W.x, W.y, W.z, 0.0f);
 }
 constexpr uint32_t kHolePixel = 0xffffffffu; // a reserved but unused ShadeTask slot
-
 // Advances every lane from "its ray has been traced" (PS_HIT) to its next ray (PS_TRACE) or the end
 // of its pixel (PS_DONE), appending the shade / leaf tasks met on the way.  Every thread of the workgroup must call it
 // (the passes are workgroup-convergent: queue slots are reserved per workgroup).  s_n: 12 words, s_base: 3 words of LDS.
@@ -932,44 +944,64 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 const vec3 fW = make3(f0.x, f0.y, f0.z), ks = make3(f3.x, f3.y, f3.z);
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
                 const vec3 cw = fW * ks / float(N);
-                uint32_t hitsSoFar = 0, nShade = 0, nLeaf = 0;
                 const bool room = shadeBase != 0xffffffffu && leafBase != 0xffffffffu;
                 if (!room) cDrop++;
-                for (uint32_t i = 0; i < N; i++) {
+                // Only the sampler's progress is needed before the pixel's next ray can start, and it depends on which
+                // candidates hit a reflecting surface.  (1) That one bit per candidate, all loads in flight together:
+                uint32_t opensMask = 0;
+                {
+                    uint32_t ctri[kMaxBatchRays], cmesh[kMaxBatchRays];
+#pragma unroll
+                    for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < P.batchRays) ? P.hits[L.rayBase + c].tri : kNoHit;
+#pragma unroll
+                    for (uint32_t c = 0; c < kMaxBatchRays; c++) cmesh[c] = (ctri[c] < kSphereBase) ? S.triAttr[ctri[c]].meshID : 0u;
+#pragma unroll
+                    for (uint32_t c = 0; c < kMaxBatchRays; c++) {
+                        if (ctri[c] == kNoHit) continue;
+                        const float* mks = (ctri[c] < kSphereBase) ? S.materials[cmesh[c]].ks : S.spheres[ctri[c] - kSphereBase].ks;
+                        if ((mks[0] != 0.0f) || (mks[1] != 0.0f) || (mks[2] != 0.0f)) opensMask |= 1u << c;
+                    }
+                    if (!F.enableReflections) opensMask = 0;
+                }
+                // (2) the candidate that stands for sample i: one place further for every earlier sample with a loop of its own
+                constexpr uint32_t kMaxN = 5; // N (N + 1) / 2 <= kMaxBatchRays
+                uint32_t ksel[kMaxN];
+                {
+                    uint32_t opened = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < kMaxN; i++) {
+                        ksel[i] = i * (i + 1) / 2 + opened;
+                        if (i < N) opened += (opensMask >> ksel[i]) & 1u;
+                    }
+                }
+                // (3) their rays and hits; what the hits look like (normal, material) is worked out by shade_expand_kernel
+                float4 ra[kMaxN], rb[kMaxN];
+                HitRec hr[kMaxN];
+#pragma unroll
+                for (uint32_t i = 0; i < kMaxN; i++) {
+                    if (i >= N) continue;
+                    const float4* rq = reinterpret_cast<const float4*>(P.pathRaysIn + L.rayBase + ksel[i]);
+                    ra[i] = rq[0], rb[i] = rq[1];
+                    hr[i] = P.hits[L.rayBase + ksel[i]];
+                }
+                uint32_t nShade = 0, nLeaf = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < kMaxN; i++) {
+                    if (i >= N) continue;
                     (void)sampler_next(L.smp); // the sample's own two draws (its direction is in the stored ray)
                     (void)sampler_next(L.smp);
-                    const uint32_t k = i * (i + 1) / 2 + hitsSoFar;
-                    const float4* rq = reinterpret_cast<const float4*>(P.pathRaysIn + L.rayBase + k);
-                    const float4 ra = rq[0], rb = rq[1];
-                    if (ra.w < 0.0f) continue; // rejected sample
+                    if (ra[i].w < 0.0f) continue; // rejected sample
                     cSecondary++;
-                    const HitRec hr = P.hits[L.rayBase + k];
-                    if (hr.tri == kNoHit) continue;
-                    const vec3 co = make3(ra.x, ra.y, ra.z), cd = make3(rb.x, rb.y, rb.z);
-                    Hit h;
-                    fill_hit(S, F, hr.tri, co, cd, hr.t, h);
-                    const vec3 p = co + hr.t * cd;
-                    if (room) store_shade_task(P.shadeQ + shadeBase + nShade, L.pixel, h.mesh | (h.isSphere ? 0x80000000u : 0u), L.smp, hr.tri, cw, p, cd, h.normal);
+                    if (hr[i].tri == kNoHit) continue;
+                    const bool opens = ((opensMask >> ksel[i]) & 1u) != 0;
+                    if (room)
+                        store_raw_shade_task(P.shadeQ + shadeBase + nShade, L.pixel, L.smp, hr[i].tri, cw, make3(ra[i].x, ra[i].y, ra[i].z),
+                                             make3(rb[i].x, rb[i].y, rb[i].z), hr[i].t, opens ? leafBase + nLeaf : 0xffffffffu);
                     nShade++;
-                    if (!F.enableReflections) continue;
-                    const Mat m = load_material(S, h.mesh, h.isSphere);
-                    if (!((m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f))) continue;
-                    // the child's own glossy loop: its children sit at the recursion limit
-                    vec3 rorg = p;
-                    const vec3 rdir = cd - 2.f * dot(cd, h.normal) * h.normal;
-                    rorg = rorg + 0.00001f * rdir;
-                    const float radius = 0.5f / m.shininess;
-                    vec3 w, u, v;
-                    ortho_basis(rdir, w, u, v);
-                    const vec3 lw = cw * m.ks / float(N);
-                    for (uint32_t s2 = 0; s2 < N; s2++) {
-                        vec3 pd;
-                        if (!glossy_sample(L.smp, radius, w, u, v, h.normal, pd)) continue;
-                        cSecondary++;
-                        if (room) store_leaf_task(P.leafQ + leafBase + nLeaf, L.pixel, rorg + 0.0001f * pd, pd, FLT_MAX, lw);
-                        nLeaf++;
-                    }
-                    hitsSoFar++;
+                    if (!opens) continue;
+                    // the child's own glossy loop: its children sit at the recursion limit and draw nothing further
+                    nLeaf += N;
+                    for (uint32_t z = 0; z < 2 * N; z++) (void)sampler_next(L.smp);
                 }
                 if (room) { // unused reserved slots stay in the queues as holes
                     for (uint32_t z = nShade; z < N; z++) reinterpret_cast<float4*>(P.shadeQ + shadeBase + z)[0] = make_float4(__uint_as_float(kHolePixel), 0.0f, 0.0f, 0.0f);
@@ -1450,6 +1482,53 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
         }
     }
     if (COUNT) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
+}
+
+// Completes the raw tasks of the shade queue (store_raw_shade_task): renderRay after the intersection for a child of a
+// batched glossy loop (src/recursive.cpp:29-36, 62-80; src/extra.cpp:464-508), everything but the sampler's progress.
+__global__ __launch_bounds__(kBlock) void shade_expand_kernel(const WaveParams P)
+{
+    const SceneView& S = P.S;
+    const uint32_t total = min(P.qCount[0], P.shadeCap);
+    const uint32_t N = P.F.numGlossySamples;
+    TraceCounters tc { 0, 0, 0 };
+    uint32_t cSecondary = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const float4* q = reinterpret_cast<const float4*>(P.shadeQ + i);
+        const float4 a = q[0];
+        if (__float_as_uint(a.y) != kRawShade || __float_as_uint(a.x) == kHolePixel) continue;
+        const float4 b = q[1], c = q[2], d = q[3];
+        const uint32_t pixel = __float_as_uint(a.x), smp = __float_as_uint(a.z), tri = __float_as_uint(a.w);
+        const vec3 W = make3(b.x, b.y, b.z), co = make3(b.w, c.x, c.y), cd = make3(c.z, c.w, d.x);
+        const float t = d.y;
+        const uint32_t leafSlot = __float_as_uint(d.z);
+        Hit h;
+        fill_hit(S, P.F, tri, co, cd, t, h);
+        const vec3 p = co + t * cd;
+        store_shade_task(P.shadeQ + i, pixel, h.mesh | (h.isSphere ? 0x80000000u : 0u), smp, tri, W, p, cd, h.normal);
+        if (leafSlot == 0xffffffffu) continue;
+        const Mat m = load_material(S, h.mesh, h.isSphere);
+        // generateReflectionRay (src/recursive.cpp:91-103)
+        vec3 rorg = p;
+        const vec3 rdir = cd - 2.f * dot(cd, h.normal) * h.normal;
+        rorg = rorg + 0.00001f * rdir;
+        // renderRayGlossyComponent's loop (src/extra.cpp:489-505): sample s to slot s, a hole where it is rejected
+        const float radius = 0.5f / m.shininess;
+        const vec3 lw = W * m.ks / float(N);
+        vec3 w, u, v;
+        ortho_basis(rdir, w, u, v);
+        uint32_t s2 = smp;
+        for (uint32_t k = 0; k < N; k++) {
+            vec3 pd;
+            if (glossy_sample(s2, radius, w, u, v, h.normal, pd)) {
+                cSecondary++;
+                store_leaf_task(P.leafQ + leafSlot + k, pixel, rorg + 0.0001f * pd, pd, FLT_MAX, lw);
+            } else {
+                store_leaf_task(P.leafQ + leafSlot + k, kHolePixel, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, splat(0.0f));
+            }
+        }
+    }
+    flush_counters(P.stats, threadIdx.x & 63, 0, 0, cSecondary, tc, 0, 0);
 }
 
 // Deferred rays at the recursion limit: a hit becomes a ShadeTask.
