@@ -731,6 +731,8 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
     do {
         bool wantShade = false, wantLeaf = false, wantFrames = false, wantBatch = false, wantConsume = false;
         bool openLoop = false; // push a glossy frame after this pass's shade task has been appended
+        uint32_t hitMask = 0, opensMask = 0, nHits = 0, nOpened = 0; // of a batch whose candidates are back (PS_BATCH)
+        constexpr uint32_t kMaxN = 5; // N (N + 1) / 2 <= kMaxBatchRays
         while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames && !wantBatch && !wantConsume) {
             switch (L.state) {
             case PS_HIT: {
@@ -850,7 +852,33 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 }
                 break;
             }
-            case PS_BATCH: wantConsume = true; break;
+            case PS_BATCH: {
+                // The traced candidates are back.  Only the sampler's progress is needed before the pixel's next ray can
+                // start, and it depends on which candidates hit a reflecting surface: that bit per candidate, all loads
+                // in flight together.
+                const uint32_t N = F.numGlossySamples;
+                uint32_t ctri[kMaxBatchRays], cmesh[kMaxBatchRays];
+#pragma unroll
+                for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < P.batchRays) ? P.hits[L.rayBase + c].tri : kNoHit;
+#pragma unroll
+                for (uint32_t c = 0; c < kMaxBatchRays; c++) cmesh[c] = (ctri[c] < kSphereBase) ? S.triAttr[ctri[c]].meshID : 0u;
+#pragma unroll
+                for (uint32_t c = 0; c < kMaxBatchRays; c++) {
+                    if (ctri[c] == kNoHit) continue;
+                    hitMask |= 1u << c;
+                    const float* mks = (ctri[c] < kSphereBase) ? S.materials[cmesh[c]].ks : S.spheres[ctri[c] - kSphereBase].ks;
+                    if ((mks[0] != 0.0f) || (mks[1] != 0.0f) || (mks[2] != 0.0f)) opensMask |= 1u << c;
+                }
+                if (!F.enableReflections) opensMask = 0;
+                // the candidate that stands for sample i lies one place further for every earlier sample with a loop of its own
+#pragma unroll
+                for (uint32_t i = 0; i < kMaxN; i++) {
+                    const uint32_t k = i * (i + 1) / 2 + nOpened;
+                    if (i < N) nHits += (hitMask >> k) & 1u, nOpened += (opensMask >> k) & 1u;
+                }
+                wantConsume = true;
+                break;
+            }
             default: L.state = PS_DONE; break;
             }
         }
@@ -858,8 +886,8 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         uint32_t shadeSlot = 0xffffffffu, leafSlot = 0xffffffffu, raySlot = 0xffffffffu;
         {
             const uint32_t N = F.numGlossySamples;
-            reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? N : 0u), P.qCount + 1, P.leafCap,
-                           wantLeaf ? 1u : (wantConsume ? N * N : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane, s_n,
+            reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? nHits : 0u), P.qCount + 1, P.leafCap,
+                           wantLeaf ? 1u : (wantConsume ? N * nOpened : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane, s_n,
                            s_base, shadeSlot, leafSlot, raySlot);
         }
         // ---- append the tasks produced in this pass ----
@@ -944,27 +972,8 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 const vec3 fW = make3(f0.x, f0.y, f0.z), ks = make3(f3.x, f3.y, f3.z);
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
                 const vec3 cw = fW * ks / float(N);
-                const bool room = shadeBase != 0xffffffffu && leafBase != 0xffffffffu;
+                const bool room = (nHits == 0 || shadeBase != 0xffffffffu) && (nOpened == 0 || leafBase != 0xffffffffu);
                 if (!room) cDrop++;
-                // Only the sampler's progress is needed before the pixel's next ray can start, and it depends on which
-                // candidates hit a reflecting surface.  (1) That one bit per candidate, all loads in flight together:
-                uint32_t opensMask = 0;
-                {
-                    uint32_t ctri[kMaxBatchRays], cmesh[kMaxBatchRays];
-#pragma unroll
-                    for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < P.batchRays) ? P.hits[L.rayBase + c].tri : kNoHit;
-#pragma unroll
-                    for (uint32_t c = 0; c < kMaxBatchRays; c++) cmesh[c] = (ctri[c] < kSphereBase) ? S.triAttr[ctri[c]].meshID : 0u;
-#pragma unroll
-                    for (uint32_t c = 0; c < kMaxBatchRays; c++) {
-                        if (ctri[c] == kNoHit) continue;
-                        const float* mks = (ctri[c] < kSphereBase) ? S.materials[cmesh[c]].ks : S.spheres[ctri[c] - kSphereBase].ks;
-                        if ((mks[0] != 0.0f) || (mks[1] != 0.0f) || (mks[2] != 0.0f)) opensMask |= 1u << c;
-                    }
-                    if (!F.enableReflections) opensMask = 0;
-                }
-                // (2) the candidate that stands for sample i: one place further for every earlier sample with a loop of its own
-                constexpr uint32_t kMaxN = 5; // N (N + 1) / 2 <= kMaxBatchRays
                 uint32_t ksel[kMaxN];
                 {
                     uint32_t opened = 0;
@@ -974,7 +983,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                         if (i < N) opened += (opensMask >> ksel[i]) & 1u;
                     }
                 }
-                // (3) their rays and hits; what the hits look like (normal, material) is worked out by shade_expand_kernel
+                // the samples' rays and hits; what the hits look like (normal, material) is worked out by shade_expand_kernel
                 float4 ra[kMaxN], rb[kMaxN];
                 HitRec hr[kMaxN];
 #pragma unroll
@@ -1002,10 +1011,6 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     // the child's own glossy loop: its children sit at the recursion limit and draw nothing further
                     nLeaf += N;
                     for (uint32_t z = 0; z < 2 * N; z++) (void)sampler_next(L.smp);
-                }
-                if (room) { // unused reserved slots stay in the queues as holes
-                    for (uint32_t z = nShade; z < N; z++) reinterpret_cast<float4*>(P.shadeQ + shadeBase + z)[0] = make_float4(__uint_as_float(kHolePixel), 0.0f, 0.0f, 0.0f);
-                    for (uint32_t z = nLeaf; z < N * N; z++) store_leaf_task(P.leafQ + leafBase + z, kHolePixel, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, splat(0.0f));
                 }
                 L.nRays = 1;
                 L.loopDepth = enclosing;
