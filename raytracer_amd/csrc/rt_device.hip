@@ -27,7 +27,7 @@ struct rt_scene {
     uint32_t queryDepth = 0;
     void* d_blob = nullptr; // one allocation holding every scene array
     size_t blobBytes = 0;
-    unsigned long long* d_stats = nullptr; // 8 counters
+    unsigned long long* d_stats = nullptr; // kStatCopies copies of the S_COUNT counters
     uint32_t* d_work = nullptr;            // work-fetch counter
     // lazily sized device buffers for rt_render_image
     float* d_rgb = nullptr;
@@ -96,6 +96,9 @@ constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is f
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
 enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
+// The counters exist kStatCopies times, 256 B apart; a workgroup adds to the copy of its index and rt_sync sums them.
+// (Additions to one address are served one at a time, about 9 ns each: 8,000 waves ending together would wait 70 us.)
+constexpr uint32_t kStatCopies = 64, kStatStride = 32; // stride in counters
 
 struct RenderParams {
     SceneView S;
@@ -1258,7 +1261,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
     for (int i = 0; i < 7; i++) {
         unsigned long long v = vals[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0 && v) atomicAdd(P.stats + i, v);
+        if (lane == 0 && v) atomicAdd(P.stats + (blockIdx.x % kStatCopies) * kStatStride + i, v);
     }
 }
 
@@ -1601,8 +1604,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     }
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_stats), S_COUNT * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, S_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_stats), kStatCopies * kStatStride * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_work), 256);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
@@ -1757,7 +1760,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const int myStripes = (stripes > reg.rank) ? (stripes - reg.rank + reg.world - 1) / reg.world : 0;
     const int myTileRows = myStripes * stripeTileRows;
     const uint32_t nWork = (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
-    RT_HIP(hipMemsetAsync(scene->d_stats, 0, S_COUNT * sizeof(unsigned long long), st));
+    RT_HIP(hipMemsetAsync(scene->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
     RT_HIP(hipMemsetAsync(scene->d_work, 0, 256, st));
     scene->lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
@@ -2106,8 +2109,10 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
     }
     RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     if (stats) {
-        unsigned long long h[S_COUNT];
-        RT_HIP(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        unsigned long long all[kStatCopies * kStatStride], h[S_COUNT] = {};
+        RT_HIP(hipMemcpy(all, scene->d_stats, sizeof(all), hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < kStatCopies; c++)
+            for (int i = 0; i < S_COUNT; i++) h[i] += all[c * kStatStride + i];
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
         stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
         stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;

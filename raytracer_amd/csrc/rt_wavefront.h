@@ -193,7 +193,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long* stats, const 
     for (int i = 0; i < 8; i++) {
         unsigned long long v = vals[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0 && v) atomicAdd(stats + i, v);
+        if (lane == 0 && v) atomicAdd(stats + (blockIdx.x % kStatCopies) * kStatStride + i, v);
     }
 }
 
