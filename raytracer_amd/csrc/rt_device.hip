@@ -66,7 +66,7 @@ struct rt_scene {
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
-    uint32_t queryStepBudget = 24;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
+    uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
     std::vector<int> lightTypes;
     std::vector<uint32_t> fallSlots; // d_roundCounts entries that count the last frame's fall-back queries
 };

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
         }
         if (budget != 0) { // the few long rays would hold the whole stage at one-lane speed: hand them over
             steps += kStepsPerCheck;
-            const bool giveUp = has && steps > budget;
+            const bool giveUp = has && steps > budget && exhausted && chunkNext == chunkEnd; // while idle lanes can be refilled a long ray costs nothing
             const unsigned long long gm = __ballot(giveUp);
             if (gm != 0ull) { // collected per wave in LDS, appended to the list 64 or more at a time (the list's counter is one address)
                 if (giveUp) {
