@@ -113,7 +113,7 @@ def test_full_depth_and_no_bounce(depth):
 
 @pytest.mark.parametrize("flags", [0, api.RT_RENDER_SERIAL])
 @pytest.mark.parametrize("name,W,H,n", [("cornell", 256, 256, 1), ("cornell", 256, 256, 4), ("monkey", 320, 180, 4), ("teapot", 320, 180, 4),
-                                        ("knot", 240, 136, 3)])
+                                        ("knot", 240, 136, 3), ("cornell", 160, 160, 2), ("monkey", 200, 112, 5), ("knot", 160, 90, 6)])
 def test_glossy_reflections_same_sampler_sequence(name, W, H, n, flags):
     """configs[3] shape: glossy multi-sample, 4 bounces.  Equal ray counts show the per-pixel sampler is
     consumed in the reference's order (rejections depend on the drawn numbers)."""
