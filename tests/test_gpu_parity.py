@@ -376,6 +376,28 @@ def test_unnested_caller_tree_is_walked_as_given():
     compare_frames(a, o.render(co, fo, 320, 180, start_depth=3), "monkey, unnested caller tree")
 
 
+@pytest.mark.parametrize("knobs", [dict(RT_AMD_T1="1"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET="2"), dict(RT_AMD_T1="1", RT_AMD_BUDGET="4", RT_AMD_NO_QUERY_TREE="1"),
+                                   dict(RT_AMD_T1="4096"), dict(RT_AMD_GROUP_LANES="16"), dict(RT_AMD_GROUP_LANES="4"), dict(RT_AMD_GROUP_LANES="32"),
+                                   dict(RT_AMD_GROUP_LANES="1"), dict(RT_AMD_NO_BATCH="1"), dict(RT_AMD_QLEAF="2"), dict(RT_AMD_TRACE_BLOCKS="1", RT_AMD_T1="1")])
+def test_tuning_knobs_change_nothing(knobs, monkeypatch):
+    """Every schedule the tuning knobs select (one ray per lane with rays handed over after a few steps, other group
+    widths, no candidate batches, another query tree) renders the frame of the default schedule bit for bit: small
+    scenes never reach the ray counts at which the default switches schedules by itself."""
+    _, _, sc = scene_pair("knot")
+    W, H = 320, 180
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)
+    cg, _ = both_cameras(W, H, dist=2.0)
+    base = scene_pair("knot")[0].render_image(cg, fg, W, H, start_depth=2)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])  # the knobs are read here
+    got = g.render_image(cg, fg, W, H, start_depth=2)
+    assert np.array_equal(got["prim"], base["prim"]) and np.array_equal(got["t"].view(np.uint32), base["t"].view(np.uint32))
+    assert (got["stats"].primaryRays, got["stats"].shadowRays, got["stats"].secondaryRays) == \
+           (base["stats"].primaryRays, base["stats"].shadowRays, base["stats"].secondaryRays)
+    assert np.array_equal(got["rgb"].view(np.uint32), base["rgb"].view(np.uint32))
+
+
 def test_slab_division_is_exact():
     """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
     total = 0
