@@ -74,7 +74,7 @@ def assert_ray_counts(gs, os_, what):
 @pytest.mark.parametrize("name,W,H", [("cornell", 512, 512), ("monkey", 640, 360), ("teapot", 640, 360), ("knot", 480, 270)])
 @pytest.mark.parametrize("flags", [0, api.RT_RENDER_NO_CULL, api.RT_RENDER_SERIAL, api.RT_RENDER_SERIAL | api.RT_RENDER_NO_CULL])
 def test_primary_hits_and_phong_frame(name, W, H, flags):
-    """configs[0]/[1] shape: Phong + shadows + mirror reflections, 2 bounces (start depth 4)."""
+    """The CPU-runnable configuration: Phong + shadows + mirror reflections, 2 bounces (start depth 4)."""
     g, o, _ = scene_pair(name)
     fg, fo = both_features()
     cg, co = both_cameras(W, H)
@@ -115,7 +115,7 @@ def test_full_depth_and_no_bounce(depth):
 @pytest.mark.parametrize("name,W,H,n", [("cornell", 256, 256, 1), ("cornell", 256, 256, 4), ("monkey", 320, 180, 4), ("teapot", 320, 180, 4),
                                         ("knot", 240, 136, 3), ("cornell", 160, 160, 2), ("monkey", 200, 112, 5), ("knot", 160, 90, 6)])
 def test_glossy_reflections_same_sampler_sequence(name, W, H, n, flags):
-    """configs[3] shape: glossy multi-sample, 4 bounces.  Equal ray counts show the per-pixel sampler is
+    """The glossy configuration at small sizes: glossy multi-sample, 4 bounces.  Equal ray counts show the per-pixel sampler is
     consumed in the reference's order (rejections depend on the drawn numbers)."""
     g, o, _ = scene_pair(name)
     fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=n)
@@ -474,7 +474,7 @@ def test_error_reporting():
 
 
 def test_headline_config_at_full_size():
-    """BASELINE's metric configuration itself: dragon stand-in (87,000 triangles), 1920x1080, glossy x4,
+    """The headline configuration itself: dragon stand-in (87,000 triangles), 1920x1080, glossy x4,
     4 bounces, bloom - against the oracle's frame, plus properties that do not depend on the oracle:
     the striped render of two ranks reassembles the frame exactly, and a second render repeats it bit for bit."""
     sc = scenes.dragon_standin()
@@ -506,7 +506,7 @@ def _dragon_pair():
 
 
 def test_teapot_and_monkey_config_at_full_size():
-    """configs[1]: teapot + monkey in one scene, 1920x1080, Phong + shadows + mirror reflections, 4 bounces."""
+    """The two-mesh configuration: teapot + monkey in one scene, 1920x1080, Phong + shadows + mirror reflections, 4 bounces."""
     sc = scenes.merge(scenes.preset("teapot"), scenes.preset("monkey"))
     g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
     o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"))
@@ -520,7 +520,7 @@ def test_teapot_and_monkey_config_at_full_size():
 
 
 def test_traversal_stress_config_at_full_size():
-    """configs[2]: dragon stand-in, 1920x1080, primary and shadow rays only."""
+    """The traversal-stress configuration: dragon stand-in, 1920x1080, primary and shadow rays only."""
     g, o, _ = _dragon_pair()
     W, H = 1920, 1080
     fg, fo = both_features(enableReflections=0)
@@ -534,7 +534,7 @@ def test_traversal_stress_config_at_full_size():
 
 @pytest.mark.parametrize("rot_y", [110.0, 245.0])
 def test_camera_sweep_frame_at_4k(rot_y):
-    """configs[4]: one frame of the 3840x2160 camera sweep (glossy x4, 4 bounces, bloom), rendered as the
+    """The camera-sweep configuration: one frame of the 3840x2160 camera sweep (glossy x4, 4 bounces, bloom), rendered as the
     two stripes two ranks would take and as one frame; both against the oracle's frame."""
     g, o, _ = _dragon_pair()
     W, H = 3840, 2160
