@@ -171,7 +171,9 @@ size_t rt_bloom_scratch_bytes(int width, int height);
 int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t filterSize, float threshold,
              float intensity, const rt_region* region, void* stream);
 
-/* Wait for the work queued on `stream` by the calls above and fetch the scene's ray counters. */
+/* Wait for the work queued on `stream` by the calls above and fetch the scene's ray counters.  It also notes how many
+ * rays each round of the frame held: the next rt_render of the same size, depth, flags, features and region leaves out
+ * the launches that only serve larger rounds (a hint - the frame is the same whatever the plan says). */
 int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);
 
 /* renderImage (src/render.cpp:19-51) for host callers: render + optional bloom + copy back.

@@ -69,6 +69,12 @@ struct rt_scene {
     uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
     std::vector<int> lightTypes;
     std::vector<uint32_t> fallSlots; // d_roundCounts entries that count the last frame's fall-back queries
+    // Launch plan carried from one frame to the next: rt_sync notes how many rays every round of the frame held; the next
+    // frame of the same description (size, depth, flags, features, region) leaves out the launches that only serve
+    // larger rounds.  The plan is a hint: a round that turns out larger is still traced completely, by the group kernel alone.
+    std::vector<uint32_t> roundRays; // per path round of the frame the plan comes from
+    uint64_t planKey = 0, lastKey = 0;
+    uint32_t lastRounds = 0;
 };
 
 #define RT_HIP(call)                                                                               \
@@ -1938,6 +1944,17 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const uint32_t taskGrid = (uint32_t)scene->numCUs * 8u;
     uint32_t resolveGrid = fullGrid < taskGrid ? fullGrid : taskGrid;
     const uint32_t rounds = (uint32_t)chain; // the camera rays are the first round
+    uint64_t key = 1469598103934665603ull; // FNV-1a over what shapes the frame's rounds
+    {
+        auto mix = [&](const void* p, size_t n) {
+            const unsigned char* b = static_cast<const unsigned char*>(p);
+            for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
+        };
+        const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
+        mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
+    }
+    const bool planned = !count && key == scene->planKey && scene->roundRays.size() == rounds && !getenv("RT_AMD_NO_PLAN");
+    scene->lastKey = key, scene->lastRounds = rounds;
 
     TraceParams T;
     T.S = scene->view;
@@ -1994,7 +2011,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
     const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
         && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
-    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul) {
+    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul, bool smallRound = false) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
         T.indirect = nullptr, T.stepBudget = 0, T.longList = scene->d_longList, T.longCount = nullptr;
@@ -2009,10 +2026,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint32_t* fallCount = scene->d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
         T.runLo = scene->laneModeAbove;
-        const uint32_t budget = count ? 0u : (useQuery ? scene->queryStepBudget : scene->stepBudget);
+        const uint32_t budget = (count || smallRound) ? 0u : (useQuery ? scene->queryStepBudget : scene->stepBudget);
         T.stepBudget = budget, T.longCount = longCount;
-        launch_one(1, useQuery);
-        T.runLo = 0, T.runHi = scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
+        if (!smallRound) launch_one(1, useQuery); // the plan says few rays: the group launch takes them, however many there are
+        T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
         launch_one(scene->groupLanes, useQuery);
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
@@ -2034,7 +2051,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
     for (uint32_t r = 1; r <= rounds; r++) {
         // the camera kernel emits exactly one ray per active state and counts them once
-        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1);
+        // a round counts as small while twice the rays the plan's frame had would still go to the group kernel
+        const bool smallRound = planned && (uint64_t)scene->roundRays[r - 1] * 2u < scene->laneModeAbove;
+        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound);
         P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
         P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
         P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;
@@ -2126,6 +2145,13 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
             rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
             return RT_ERR_LIMIT;
         }
+    }
+    if (scene->lastWasWavefront && scene->lastRounds) { // the next frame's plan
+        const uint32_t n = scene->lastRounds;
+        scene->roundRays.assign(n, 0u);
+        RT_HIP(hipMemcpy(&scene->roundRays[0], scene->d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
+        if (n > 1) RT_HIP(hipMemcpy(&scene->roundRays[1], scene->d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        scene->planKey = scene->lastKey;
     }
     if (scene->lastWasWavefront) { // did every deferred task fit its queue?
         uint32_t q[2];

@@ -398,6 +398,27 @@ def test_tuning_knobs_change_nothing(knobs, monkeypatch):
     assert np.array_equal(got["rgb"].view(np.uint32), base["rgb"].view(np.uint32))
 
 
+def test_launch_plan_from_another_view_changes_nothing():
+    """rt_sync notes the ray count of every round and the next frame of the same description leaves out the launches
+    that only serve larger rounds.  A plan taken from a distant view (few rays) and used for a close one (rounds far
+    beyond what the plan expects) still renders the frame of a scene that has no plan, bit for bit."""
+    _, _, sc = scene_pair("knot")
+    W, H = 384, 216
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=4)
+    far, _ = both_cameras(W, H, dist=9.0)
+    near, _ = both_cameras(W, H, dist=2.0)
+    fresh = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    want = fresh.render_image(near, fg, W, H, start_depth=2)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    small = g.render_image(far, fg, W, H, start_depth=2)  # ends with rt_sync: the plan
+    assert small["stats"].rays * 4 < want["stats"].rays
+    got = g.render_image(near, fg, W, H, start_depth=2)
+    again = g.render_image(near, fg, W, H, start_depth=2)  # planned from the close view itself
+    for r in (got, again):
+        assert np.array_equal(r["prim"], want["prim"]) and np.array_equal(r["rgb"].view(np.uint32), want["rgb"].view(np.uint32))
+        assert r["stats"].rays == want["stats"].rays
+
+
 def test_slab_division_is_exact():
     """The traversal's division-free slab distances equal IEEE `(bound - origin) / direction` bit for bit."""
     total = 0

@@ -19,7 +19,7 @@ for world in (1, 2, 4, 8):
         reg = api.Region(8, rank, world)
         for _ in range(2):
             scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=reg, stream=stream)
-        torch.cuda.synchronize()
+        scene.sync(stream)  # as a caller reading the frame's counters does: the next frames use this frame's launch plan
         t0 = time.perf_counter()
         for _ in range(5):
             scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=reg, stream=stream)
