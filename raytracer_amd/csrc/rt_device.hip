@@ -1971,27 +1971,28 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const uint32_t groupGrid = scene->groupBlocksPerCU ? (uint32_t)scene->numCUs * scene->groupBlocksPerCU
                                                        : (scene->laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
+    uint32_t gridNow = groupGrid; // workgroups of the next group launch: fewer where few rays are expected (the rest is fetched in chunks)
     auto launch_one = [&](uint32_t groupLanes, bool query) {
         T.fetch = scene->d_roundCounts + nextFetch++;
         T.S = query ? scene->queryView : scene->view;
         if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
-            if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+            if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
             else if (groupLanes == 16)
-                hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(groupGrid), dim3(kBlock), 0, st, T, qreserve);
+                hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
             else hipLaunchKernelGGL((trace_kernel<true, false, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
             return;
         }
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
     do {                                                                                                                  \
         if (groupLanes == 4)                                                                                              \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);   \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 4>), dim3(gridNow), dim3(kBlock), 0, st, T, reserve);   \
         else if (groupLanes == 8)                                                                                         \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);   \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 8>), dim3(gridNow), dim3(kBlock), 0, st, T, reserve);   \
         else if (groupLanes == 16)                                                                                        \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);  \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 16>), dim3(gridNow), dim3(kBlock), 0, st, T, reserve);  \
         else if (groupLanes == 32)                                                                                        \
-            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(groupGrid), dim3(kBlock), 0, st, T, reserve);  \
+            hipLaunchKernelGGL((group_trace_kernel<CULL, COUNT, 32>), dim3(gridNow), dim3(kBlock), 0, st, T, reserve);  \
         else if (stackClass == 0) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
         else if (stackClass == 1) hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 24>), dim3(traceGrid), dim3(kBlock), 0, st, T); \
         else hipLaunchKernelGGL((trace_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, T);                \
@@ -2011,7 +2012,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
     const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
         && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
-    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul, bool smallRound = false) {
+    auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul, bool smallRound = false,
+                            uint32_t expected = 0) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
         T.indirect = nullptr, T.stepBudget = 0, T.longList = scene->d_longList, T.longCount = nullptr;
@@ -2030,7 +2032,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         T.stepBudget = budget, T.longCount = longCount;
         if (!smallRound) launch_one(1, useQuery); // the plan says few rays: the group launch takes them, however many there are
         T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
+        if (smallRound) gridNow = std::min(groupGrid, std::max(256u, ((2u * expected + groupRaysPerBlock - 1) / groupRaysPerBlock + 7u) & ~7u));
         launch_one(scene->groupLanes, useQuery);
+        gridNow = groupGrid;
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
             T.indirect = scene->d_longList;
@@ -2041,7 +2045,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             T.runLo = 0, T.runHi = 0xffffffffu;
             T.indirect = scene->d_fallList;
             T.countPtr = fallCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
+            gridNow = std::min(groupGrid, 256u); // a handful of rays as a rule
             launch_one(scene->groupLanes, false);
+            gridNow = groupGrid;
         }
     };
 
@@ -2053,7 +2059,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         // the camera kernel emits exactly one ray per active state and counts them once
         // a round counts as small while twice the rays the plan's frame had would still go to the group kernel
         const bool smallRound = planned && (uint64_t)scene->roundRays[r - 1] * 2u < scene->laneModeAbove;
-        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound);
+        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
+                     smallRound ? scene->roundRays[r - 1] : 0u);
         P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
         P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
         P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;
