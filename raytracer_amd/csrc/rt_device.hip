@@ -2057,8 +2057,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
     for (uint32_t r = 1; r <= rounds; r++) {
         // the camera kernel emits exactly one ray per active state and counts them once
-        // a round counts as small while twice the rays the plan's frame had would still go to the group kernel
-        const bool smallRound = planned && (uint64_t)scene->roundRays[r - 1] * 2u < scene->laneModeAbove;
+        // a round counts as small when the plan's frame would have sent it to the group kernel (which is about as fast as the
+        // other schedule up to half as many rays again, should this frame's round be larger)
+        const bool smallRound = planned && scene->roundRays[r - 1] < scene->laneModeAbove;
         launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
                      smallRound ? scene->roundRays[r - 1] : 0u);
         P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
