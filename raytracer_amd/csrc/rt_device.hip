@@ -2160,6 +2160,13 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
         RT_HIP(hipMemcpy(&scene->roundRays[0], scene->d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
         if (n > 1) RT_HIP(hipMemcpy(&scene->roundRays[1], scene->d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         scene->planKey = scene->lastKey;
+        if (getenv("RT_AMD_VERBOSE")) { // rays traced by the path rounds (candidate batches included), round by round
+            unsigned long long sum = 0;
+            for (uint32_t v : scene->roundRays) sum += v;
+            fprintf(stderr, "rt_amd: %u path rounds traced %llu rays:", n, sum);
+            for (uint32_t v : scene->roundRays) fprintf(stderr, " %u", v);
+            fprintf(stderr, "\n");
+        }
     }
     if (scene->lastWasWavefront) { // did every deferred task fit its queue?
         uint32_t q[2];
