@@ -64,6 +64,7 @@ struct rt_scene {
     uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
     uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
+    uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
@@ -1657,6 +1658,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s\n",
                 nTris, nPairs, flat.maxDepth, nQPairs, qt.pairDepth, nQNodes, qt.maxDepth, qt.usable ? "" : " (not used)");
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
@@ -2032,8 +2034,11 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         T.stepBudget = budget, T.longCount = longCount;
         if (!smallRound) launch_one(1, useQuery); // the plan says few rays: the group launch takes them, however many there are
         T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
-        if (smallRound) gridNow = std::min(groupGrid, std::max(256u, ((2u * expected + groupRaysPerBlock - 1) / groupRaysPerBlock + 7u) & ~7u));
-        launch_one(scene->groupLanes, useQuery);
+        // a round of few rays is bound by its longest ray: 16 lanes per ray shorten that chain (more rays: fewer rays per wave cost more)
+        const bool wide = smallRound && useQuery && scene->groupLanes == 8 && expected < scene->wideBelow;
+        const uint32_t rpb = wide ? groupRaysPerBlock / 2 : groupRaysPerBlock;
+        if (smallRound) gridNow = std::min(wide ? 2 * groupGrid : groupGrid, std::max(256u, ((2u * expected + rpb - 1) / rpb + 7u) & ~7u));
+        launch_one(wide ? 16u : scene->groupLanes, useQuery);
         gridNow = groupGrid;
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
