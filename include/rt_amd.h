@@ -171,6 +171,17 @@ size_t rt_bloom_scratch_bytes(int width, int height);
 int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t filterSize, float threshold,
              float intensity, const rt_region* region, void* stream);
 
+/* rt_bloom over the whole frame for callers that cannot allocate device memory or pass a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * intermediate image lives in a static device array of the library (3 * RT_BLOOM_STATIC_MAX_PIXELS floats = 24 MiB on
+ * every GPU the library runs on, held until the process ends); the call allocates and frees nothing.  Frames of more
+ * than RT_BLOOM_STATIC_MAX_PIXELS pixels are rejected with RT_ERR_LIMIT.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams, two threads) race; calls queued on one stream do not.  Results are
+ * those of rt_bloom bit for bit. */
+#define RT_BLOOM_STATIC_MAX_PIXELS (1u << 21) /* 2,097,152: a 1920x1080 frame fits */
+int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, float threshold, float intensity,
+                    void* stream);
+
 /* Wait for the work queued on `stream` by the calls above and fetch the scene's ray counters.  It also notes how many
  * rays each round of the frame held: the next rt_render of the same size, depth, flags, features and region leaves out
  * the launches that only serve larger rounds (a hint - the frame is the same whatever the plan says). */

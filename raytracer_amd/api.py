@@ -16,6 +16,7 @@ u32p = C.POINTER(C.c_uint32)
 
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT = range(6)
 RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_TREE = 1, 2, 4, 8
+RT_BLOOM_STATIC_MAX_PIXELS = 1 << 21
 NO_HIT = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -111,6 +112,7 @@ def lib():
     L.rt_bloom_scratch_bytes.restype = C.c_size_t
     L.rt_bloom_scratch_bytes.argtypes = [C.c_int, C.c_int]
     L.rt_bloom.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float, C.POINTER(Region), vp]
+    L.rt_bloom_static.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float, vp]
     L.rt_sync.argtypes = [vp, vp, C.POINTER(Stats)]
     L.rt_render_image.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.c_uint32, f32p, u32p,
                                   f32p, C.POINTER(Stats)]
@@ -263,3 +265,8 @@ class Scene:
 
 def bloom_device(d_rgb, d_scratch, W, H, F=15, threshold=0.5, intensity=0.8, region=None, stream=None):
     check(lib().rt_bloom(d_rgb, d_scratch, W, H, F, threshold, intensity, C.byref(region) if region else None, stream))
+
+
+def bloom_static(d_rgb, W, H, F=15, threshold=0.5, intensity=0.8, stream=None):
+    """rt_bloom_static: the whole frame, intermediate image in the library's static device array."""
+    check(lib().rt_bloom_static(d_rgb, W, H, F, threshold, intensity, stream))

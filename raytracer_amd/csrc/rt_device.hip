@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1327,6 +1328,13 @@ struct BloomParams {
     float taps[2 * kBloomMaxF + 1];
 };
 
+// Scratch of rt_bloom_static: the row-filtered image of the largest frame that entry point accepts.  One copy per GPU
+// that loads the library, held until the process ends; kernels receive its device address as an argument.
+static __device__ __align__(256) float g_bloomScratch[3ull * RT_BLOOM_STATIC_MAX_PIXELS];
+constexpr int kMaxDevices = 64;
+float* g_bloomScratchPtr[kMaxDevices] = {}; // device address of g_bloomScratch per device (hipGetSymbolAddress)
+std::mutex g_bloomScratchMutex;
+
 constexpr int kBloomRowTile = 256;
 // pass 1: threshold (applyThreshold, :186-196) + filter along x (applyFilter1dToPixel toRow, :307-314)
 __global__ __launch_bounds__(kBloomRowTile) void bloom_rows_kernel(const BloomParams P)
@@ -2131,6 +2139,41 @@ int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t fil
                        dim3(kBloomColX * 4), 0, st, P);
     RT_HIP(hipGetLastError());
     return RT_OK;
+}
+
+// rt_bloom for callers that cannot allocate: the row-filtered intermediate image lives in a file-scope device array.
+// Each GPU holds its own copy of the array at its own address, looked up once per device; host code never uses the
+// array's name for anything else (on the host the name is a stand-in, not a device address).
+int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, float threshold, float intensity, void* stream)
+{
+    if (!d_rgb || width <= 0 || height <= 0) {
+        rt::set_error("rt_bloom_static: null argument or empty frame");
+        return RT_ERR_INVALID;
+    }
+    if ((unsigned long long)width * (unsigned long long)height > RT_BLOOM_STATIC_MAX_PIXELS) {
+        rt::set_error("rt_bloom_static: a frame of %dx%d pixels exceeds the static scratch array of %llu pixels - use rt_bloom with "
+                      "a workspace of rt_bloom_scratch_bytes()",
+                      width, height, (unsigned long long)RT_BLOOM_STATIC_MAX_PIXELS);
+        return RT_ERR_LIMIT;
+    }
+    int device = -1;
+    RT_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) {
+        rt::set_error("rt_bloom_static: device %d outside [0,%d)", device, kMaxDevices);
+        return RT_ERR_LIMIT;
+    }
+    float* scratch = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_bloomScratchMutex);
+        if (!g_bloomScratchPtr[device]) { // first call on this device, which is the current one
+            void* p = nullptr;
+            RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_bloomScratch)));
+            g_bloomScratchPtr[device] = static_cast<float*>(p);
+        }
+        scratch = g_bloomScratchPtr[device];
+    }
+    // pass 1 writes every pixel of the intermediate image that pass 2 reads: nothing of an earlier call is read
+    return rt_bloom(d_rgb, scratch, width, height, filterSize, threshold, intensity, nullptr, stream);
 }
 
 int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
