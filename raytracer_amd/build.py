@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librt_amd.so")
 SOURCES = ["rt_device.hip", "host_bvh.cpp"]
-HEADERS = ["rt_types.h", "rt_math.h", os.path.join("..", "..", "include", "rt_amd.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "rt_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"]
 

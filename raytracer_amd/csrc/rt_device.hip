@@ -103,7 +103,7 @@ constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per ch
 constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is followed through (transparent shadows)
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
-enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_COUNT = 8 };
+enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_BIGVALUE, S_COUNT = 9 };
 // The counters exist kStatCopies times, 256 B apart; a workgroup adds to the copy of its index and rt_sync sums them.
 // (Additions to one address are served one at a time, about 9 ns each: 8,000 waves ending together would wait 70 us.)
 constexpr uint32_t kStatCopies = 64, kStatStride = 32; // stride in counters
@@ -1918,7 +1918,12 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             if (!features->enableReflections) break;
         }
         if (chain < 1) chain = 1;
+        // rays per pixel as pixel_ray_count has them: generatePixelRaysStratified takes round(sqrt(N))^2 (src/render.cpp:100-123)
         uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
+        if (features->numPixelSamples > 1 && features->enableJitteredSampling) {
+            const uint64_t ns = (uint64_t)roundf(sqrtf((float)features->numPixelSamples));
+            nRays = ns * ns;
+        }
         chain *= nRays;
     }
     if (chain > kMaxRounds - 1 || 6 * nChunks + 32 > kMaxTraceLaunches - 6 * kMaxRounds) {
@@ -2183,11 +2188,14 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
         return RT_ERR_INVALID;
     }
     RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    if (stats) {
-        unsigned long long all[kStatCopies * kStatStride], h[S_COUNT] = {};
+    unsigned long long h[S_COUNT] = {};
+    {
+        unsigned long long all[kStatCopies * kStatStride];
         RT_HIP(hipMemcpy(all, scene->d_stats, sizeof(all), hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < kStatCopies; c++)
             for (int i = 0; i < S_COUNT; i++) h[i] += all[c * kStatStride + i];
+    }
+    if (stats) {
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
         stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
         stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;
@@ -2197,8 +2205,27 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
             RT_HIP(hipMemcpy(c.data(), scene->d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (uint32_t slot : scene->fallSlots) stats->referenceTreeQueries += c[slot - lo];
         }
-        if (h[S_OVERFLOW]) {
-            rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
+    }
+    if (h[S_OVERFLOW]) {
+        rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
+        return RT_ERR_LIMIT;
+    }
+    if (h[S_DROPPED]) {
+        rt::set_error("%llu rays or tasks found no room in the frame's buffers: the frame is incomplete; render with RT_RENDER_SERIAL "
+                      "or in smaller regions", h[S_DROPPED]);
+        return RT_ERR_LIMIT;
+    }
+    if (h[S_BIGVALUE]) {
+        rt::set_error("%llu finite contributions of magnitude >= 4e6 exceed the fixed-point pixel sums (recorded as infinite): render "
+                      "with RT_RENDER_SERIAL", h[S_BIGVALUE]);
+        return RT_ERR_LIMIT;
+    }
+    if (scene->lastWasWavefront && scene->lastRounds) { // a pixel still had rays to trace when the rounds ended
+        uint32_t left = 0;
+        RT_HIP(hipMemcpy(&left, scene->d_roundCounts + scene->lastRounds, sizeof(left), hipMemcpyDeviceToHost));
+        if (left) {
+            rt::set_error("%u pixels were unfinished after the frame's %u path rounds: the frame is incomplete; render with RT_RENDER_SERIAL",
+                          left, scene->lastRounds);
             return RT_ERR_LIMIT;
         }
     }
@@ -2250,6 +2277,8 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
     }
     int rc = rt_render(scene, camera, features, width, height, startDepth, nullptr, flags, scene->d_rgb, primId ? scene->d_primId : nullptr,
                        primT ? scene->d_primT : nullptr, nullptr);
+    if (rc == RT_ERR_LIMIT && !(flags & RT_RENDER_SERIAL)) // a frame beyond the default pipeline's limits: evaluate it depth-first instead
+        return rt_render_image(scene, camera, features, width, height, startDepth, flags | RT_RENDER_SERIAL, rgb, primId, primT, stats);
     if (rc != RT_OK) return rc;
     if (features->enableBloomEffect) { // src/render.cpp:48-50
         rc = rt_bloom(scene->d_rgb, scene->d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,

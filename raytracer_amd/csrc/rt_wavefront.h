@@ -108,6 +108,8 @@ __device__ __forceinline__ void accumulate_pixel(const WaveParams& P, const uint
         } else {
             const uint32_t bit = (x != x) ? (1u << ch) : (x > 0.0f ? (8u << ch) : (64u << ch));
             atomicOr(P.nonfinite + pixel, bit);
+            // a finite value this large does not fit the fixed-point sum: the frame is reported incomplete (rt_sync)
+            if (fabsf(x) <= FLT_MAX) atomicAdd(P.stats + (blockIdx.x % kStatCopies) * kStatStride + S_BIGVALUE, 1ull);
         }
     }
 }

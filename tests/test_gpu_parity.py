@@ -175,6 +175,24 @@ def test_multisampled_pixels():
         assert rg["stats"].primaryRays == ro["stats"]["primary"] == 4 * 128 * 128
 
 
+@pytest.mark.parametrize("reflections", [0, 1])
+def test_jittered_sample_count_that_is_no_square(reflections):
+    """numPixelSamples = 3 with jittered sampling takes round(sqrt(3))^2 = 4 rays per pixel (src/render.cpp:100-123): every one
+    of them must be traced and shaded by the default pipeline, not only by the depth-first one."""
+    g, o, _ = scene_pair("cornell")
+    cg, co = both_cameras(96, 96)
+    fg, fo = both_features(numPixelSamples=3, enableJitteredSampling=1, enableReflections=reflections)
+    rg, ro = g.render_image(cg, fg, 96, 96, start_depth=4), o.render(co, fo, 96, 96, start_depth=4)
+    rs = g.render_image(cg, fg, 96, 96, start_depth=4, flags=api.RT_RENDER_SERIAL)
+    e = rmse(rg["rgb"], ro["rgb"])
+    print(e, rg["stats"].as_dict())
+    assert (e <= RMSE_TOL).all()
+    assert rg["stats"].primaryRays == ro["stats"]["primary"] == 4 * 96 * 96
+    assert rg["stats"].shadowRays == ro["stats"]["shadow"] == rs["stats"].shadowRays
+    assert rg["stats"].secondaryRays == ro["stats"]["secondary"]
+    assert np.abs(rg["rgb"] - rs["rgb"]).max() < 1e-5
+
+
 def test_brute_force_matches_bvh():
     """enableAccelStructure off (the reference's own InterfaceTest configuration)."""
     g, o, _ = scene_pair("cornell")
