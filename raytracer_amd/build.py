@@ -36,5 +36,5 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True, extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
+    build(force="--force" in sys.argv, verbose=True, extra=[a for a in sys.argv[1:] if a.startswith(("-R", "-save", "-D"))])
     print(LIB)

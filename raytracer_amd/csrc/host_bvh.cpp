@@ -495,6 +495,34 @@ void build_query_tree(const FlatScene& flat, QueryTree& out)
         c.compact = t;
         c.route = flat.leafRoute[t];
     }
+    // the 4-wide form once more, for four lanes per ray
+    out.quadNodes.clear(), out.quadLeaves.clear();
+    if (qb.kLeaf <= 4) {
+        out.quadNodes.resize(out.nodes.size());
+        for (size_t i = 0; i < out.nodes.size(); i++) {
+            const Node4& nd = out.nodes[i];
+            QuadNode& qn = out.quadNodes[i];
+            for (int k = 0; k < 4; k++) {
+                QuadChild& c = qn.c[k];
+                c.lo[0] = nd.lox[k], c.lo[1] = nd.loy[k], c.lo[2] = nd.loz[k];
+                c.hi[0] = nd.hix[k], c.hi[1] = nd.hiy[k], c.hi[2] = nd.hiz[k];
+                c.ref = nd.ref[k], c.pad = 0;
+                if (nd.ref[k] == kEmptyRef || !(nd.ref[k] & kLeafBit)) continue;
+                const uint32_t first = nd.ref[k] & kRefOffsetMask, cnt = (nd.ref[k] >> kRefCountShift) & kMaxLeafCount;
+                QuadLeaf lf;
+                memset(&lf, 0, sizeof(lf));
+                for (uint32_t t = 0; t < cnt && t < 4; t++) {
+                    memcpy(lf.plane[t], &out.triPlane[first + t], 16);
+                    const float* e = reinterpret_cast<const float*>(&out.triEdges[first + t]);
+                    for (int j = 0; j < 5; j++) memcpy(lf.e[j][t], e + 4 * j, 16);
+                    const uint32_t id = first + t;
+                    memcpy(&lf.e[4][t][2], &id, 4);
+                }
+                c.ref = kLeafBit | (cnt << kRefCountShift) | uint32_t(out.quadLeaves.size());
+                out.quadLeaves.push_back(lf);
+            }
+        }
+    }
     out.usable = true;
 }
 

@@ -11,36 +11,23 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 using namespace rt;
 
-// =============================================================================================
-// Host-side scene object
-// =============================================================================================
-struct rt_scene {
-    int device = 0;
-    SceneView view {};
-    SceneView queryView {}; // the same scene with the query tree in place of the reference's (cert != null when usable)
-    uint32_t queryDepth = 0;
-    void* d_blob = nullptr; // one allocation holding every scene array
-    size_t blobBytes = 0;
+// Everything one frame in flight needs besides the scene: counters, queues, path states.  A scene keeps one set per stream
+// that frames are queued on, so frames on different streams may overlap on the GPU (the rounds of one frame are chains of
+// short dependent launches that leave most of the chip idle; a second frame fills it).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    uint64_t lastUse = 0;
     unsigned long long* d_stats = nullptr; // kStatCopies copies of the S_COUNT counters
     uint32_t* d_work = nullptr;            // work-fetch counter
-    // lazily sized device buffers for rt_render_image
-    float* d_rgb = nullptr;
-    float* d_scratch = nullptr;
-    uint32_t* d_primId = nullptr;
-    float* d_primT = nullptr;
-    size_t fbPixels = 0;
-    bool hasTextures = false;
-    GpuTexture* d_textures = nullptr;  // one entry per material (part of no blob: rt_scene_set_texture rewrites entries)
-    std::vector<float*> texturePixels; // device copy of each material's texels (null: none)
-    uint32_t treeDepth = 0;
-    int numCUs = 256;
     // wavefront pipeline buffers (sized on demand by rt_render)
     long long* d_accum = nullptr;
     uint32_t* d_nonfinite = nullptr;
@@ -62,14 +49,8 @@ struct rt_scene {
     uint32_t* d_fallList = nullptr; // indices of the rays a query-tree launch could not settle (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
-    uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
-    uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
-    uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
-    uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
-    uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
-    uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
-    uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
-    std::vector<int> lightTypes;
+    uint32_t dbgWaves = 0;
+    std::vector<uint32_t> sliceSlots; // d_roundCounts entries that count the pixels every slice of the path stage set aside
     std::vector<uint32_t> fallSlots; // d_roundCounts entries that count the last frame's fall-back queries
     // Launch plan carried from one frame to the next: rt_sync notes how many rays every round of the frame held; the next
     // frame of the same description (size, depth, flags, features, region) leaves out the launches that only serve
@@ -78,6 +59,57 @@ struct rt_scene {
     uint64_t planKey = 0, lastKey = 0;
     uint32_t lastRounds = 0;
 };
+
+struct RetiredFrame {
+    hipStream_t stream;
+    rt_stats stats;
+    int status;
+    std::string message;
+};
+
+// =============================================================================================
+// Host-side scene object
+// =============================================================================================
+struct rt_scene {
+    int device = 0;
+    SceneView view {};
+    SceneView queryView {}; // the same scene with the query tree in place of the reference's (cert != null when usable)
+    uint32_t queryDepth = 0;
+    void* d_blob = nullptr; // one allocation holding every scene array
+    size_t blobBytes = 0;
+    // lazily sized device buffers for rt_render_image
+    float* d_rgb = nullptr;
+    float* d_scratch = nullptr;
+    uint32_t* d_primId = nullptr;
+    float* d_primT = nullptr;
+    size_t fbPixels = 0;
+    bool hasTextures = false;
+    GpuTexture* d_textures = nullptr;  // one entry per material (part of no blob: rt_scene_set_texture rewrites entries)
+    std::vector<float*> texturePixels; // device copy of each material's texels (null: none)
+    uint32_t treeDepth = 0;
+    std::vector<RetiredFrame> retired; // what rt_sync reports for streams whose buffers were taken over
+    std::vector<struct Workspace*> workspaces; // per-frame buffers, one set per stream that frames are queued on (see workspace_for)
+    uint64_t useCounter = 0;
+    int numCUs = 256;
+    uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
+    uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
+    uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
+    uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
+    uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
+    uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
+    uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
+    bool quadTrace = false;          // group launches in a query tree run four lanes per ray (RT_AMD_QUAD_TRACE; default: 8 or 16)
+    int pathQuads = 0;               // pixel-per-lane mode with a query tree: 1 = four lanes per pixel (frames in LDS), 2 = the same with frames in
+                                     // global memory, 0 = one lane per pixel (RT_AMD_PATH_QUADS)
+    int pathMode = 0;                // path stage: 0 = frame-wide rounds (and 2 for frames whose chains exceed the rounds' limit); 2 = one
+                                     // persistent launch, a pixel per lane; 1 = the same, a group of lanes per pixel (RT_AMD_PATH_MODE overrides)
+    uint32_t pathBlocksPerCU = 4;    // grid of the persistent launch (RT_AMD_PATH_BLOCKS overrides)
+    uint32_t advanceAt = 16, advanceEvery = 2; // pixel per lane: see PathKParams (RT_AMD_ADVANCE_AT, RT_AMD_ADVANCE_EVERY)
+    uint32_t linkBudget = 0, minLanes = 32;   // pixel per lane, slices: see PathKParams (RT_AMD_LINK_BUDGET, 0 = one launch; RT_AMD_MIN_LANES)
+    std::vector<int> lightTypes;
+};
+
+static int collect_frame(rt_scene* scene, struct Workspace& w, rt_stats* stats);
 
 #define RT_HIP(call)                                                                               \
     do {                                                                                           \
@@ -1274,6 +1306,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
 }
 
 #include "rt_wavefront.h"
+#include "rt_path.h"
 
 // ---------------------------------------------------------------------------------------------
 // Batch closest-hit kernel (BVHInterface::intersect for n rays)
@@ -1509,6 +1542,69 @@ T* carve(char*& p, size_t n)
 }
 size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
+void free_workspace(Workspace* w)
+{
+    if (!w) return;
+    (void)hipFree(w->d_stats), (void)hipFree(w->d_work), (void)hipFree(w->d_accum), (void)hipFree(w->d_nonfinite);
+    (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states);
+    (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
+    (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
+    (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_fallList);
+    delete w;
+}
+
+constexpr size_t kMaxWorkspaces = 4;
+// The buffers of the frames queued on `stream`: frames on one stream share a set (they run one after the other anyway), a
+// stream not seen before gets its own, and beyond kMaxWorkspaces streams the set unused for longest is taken over once the
+// frames of its stream have finished.  Null (with the error set) when nothing can be allocated.
+Workspace* workspace_for(rt_scene* scene, hipStream_t stream, const bool create)
+{
+    scene->useCounter++;
+    for (Workspace* w : scene->workspaces)
+        if (w->stream == stream) {
+            w->lastUse = scene->useCounter;
+            return w;
+        }
+    if (!create) return nullptr;
+    Workspace* w = nullptr;
+    if (scene->workspaces.size() < kMaxWorkspaces) {
+        w = new (std::nothrow) Workspace();
+        if (!w) {
+            rt::set_error("out of memory");
+            return nullptr;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->d_stats), kStatCopies * kStatStride * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(w->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&w->d_work), 256);
+        if (e != hipSuccess) {
+            rt::set_error("device allocation of a frame's counters failed: %s", hipGetErrorString(e));
+            free_workspace(w);
+            return nullptr;
+        }
+        scene->workspaces.push_back(w);
+    } else {
+        w = scene->workspaces[0];
+        for (Workspace* c : scene->workspaces)
+            if (c->lastUse < w->lastUse) w = c;
+        if (hipStreamSynchronize(w->stream) != hipSuccess) {
+            rt::set_error("hipStreamSynchronize failed while taking over a frame's buffers");
+            return nullptr;
+        }
+        RetiredFrame r;
+        r.stream = w->stream;
+        r.status = collect_frame(scene, *w, &r.stats);
+        r.message = r.status != RT_OK ? rt_last_error() : "";
+        for (size_t i = 0; i < scene->retired.size(); i++)
+            if (scene->retired[i].stream == r.stream) scene->retired.erase(scene->retired.begin() + i--);
+        if (scene->retired.size() >= 64) scene->retired.erase(scene->retired.begin());
+        scene->retired.push_back(r);
+    }
+    for (size_t i = 0; i < scene->retired.size(); i++) // this stream's frames report through `w` from now on
+        if (scene->retired[i].stream == stream) scene->retired.erase(scene->retired.begin() + i--);
+    w->stream = stream, w->lastUse = scene->useCounter;
+    return w;
+}
+
 } // namespace
 
 // =============================================================================================
@@ -1570,10 +1666,12 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt);
     const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
+    const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
         + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(nMaterials * sizeof(GpuMaterial))
         + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQNodes * sizeof(Node4)) + padded(nQPairs * sizeof(NodePair))
-        + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert)) + 256;
+        + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert))
+        + padded(nQuadNodes * sizeof(QuadNode)) + padded(nQuadLeaves * sizeof(QuadLeaf)) + 256;
     std::vector<char> host(total, 0);
     char* hp = host.data();
     NodePair* hPairs = carve<NodePair>(hp, nPairs);
@@ -1589,7 +1687,11 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     TriPlane* hQPlane = carve<TriPlane>(hp, nQTris);
     TriEdges* hQEdges = carve<TriEdges>(hp, nQTris);
     TriCert* hQCert = carve<TriCert>(hp, nQTris);
+    QuadNode* hQuadNodes = carve<QuadNode>(hp, nQuadNodes);
+    QuadLeaf* hQuadLeaves = carve<QuadLeaf>(hp, nQuadLeaves);
     if (qt.usable) {
+        if (nQuadNodes) memcpy(hQuadNodes, qt.quadNodes.data(), nQuadNodes * sizeof(QuadNode));
+        if (nQuadLeaves) memcpy(hQuadLeaves, qt.quadLeaves.data(), nQuadLeaves * sizeof(QuadLeaf));
         memcpy(hQNodes, qt.nodes.data(), nQNodes * sizeof(Node4));
         memcpy(hQPairs, qt.pairs.data(), nQPairs * sizeof(NodePair));
         memcpy(hQPlane, qt.triPlane.data(), nQTris * sizeof(TriPlane));
@@ -1619,9 +1721,6 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     }
     hipError_t e = hipMalloc(&s->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_stats), kStatCopies * kStatStride * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(s->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_work), 256);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     s->texturePixels.assign(nMaterials, nullptr);
@@ -1647,7 +1746,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     const TriPlane* dQPlane = carve<TriPlane>(dp, nQTris);
     const TriEdges* dQEdges = carve<TriEdges>(dp, nQTris);
     const TriCert* dQCert = carve<TriCert>(dp, nQTris);
-    V.cert = nullptr, V.nodes4 = nullptr;
+    const QuadNode* dQuadNodes = carve<QuadNode>(dp, nQuadNodes);
+    const QuadLeaf* dQuadLeaves = carve<QuadLeaf>(dp, nQuadLeaves);
+    V.cert = nullptr, V.nodes4 = nullptr, V.quadNodes = nullptr, V.quadLeaves = nullptr;
     V.refPairs = V.pairs, V.refRootRef = flat.rootRef;
     memcpy(V.rootLo, flat.rootLo, 12);
     memcpy(V.rootHi, flat.rootHi, 12);
@@ -1658,6 +1759,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     s->queryView = V;
     if (qt.usable) { // same root box: a query starts with the reference's own root test
         s->queryView.pairs = dQPairs, s->queryView.nodes4 = dQNodes;
+        if (nQuadNodes) s->queryView.quadNodes = dQuadNodes, s->queryView.quadLeaves = dQuadLeaves;
         s->queryView.triPlane = dQPlane, s->queryView.triEdges = dQEdges, s->queryView.cert = dQCert;
         s->queryView.rootRef = qt.pairRootRef, s->queryView.nPairs = uint32_t(nQPairs); // root of the 4-wide form: node 0
         s->queryDepth = qt.pairDepth;
@@ -1675,6 +1777,14 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     }
     if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     if (const char* e = getenv("RT_AMD_GROUP_BLOCKS")) s->groupBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 0);
+    if (const char* e = getenv("RT_AMD_PATH_MODE")) s->pathMode = atoi(e);
+    if (const char* e = getenv("RT_AMD_PATH_QUADS")) s->pathQuads = atoi(e);
+    if (getenv("RT_AMD_QUAD_TRACE")) s->quadTrace = true;
+    if (const char* e = getenv("RT_AMD_LINK_BUDGET")) s->linkBudget = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_MIN_LANES")) s->minLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_ADVANCE_AT")) s->advanceAt = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_ADVANCE_EVERY")) s->advanceEvery = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_PATH_BLOCKS")) s->pathBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     for (uint32_t i = 0; i < nLights; i++) s->lightTypes.push_back((int)lights22[22 * (size_t)i]);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->numCUs = cus;
@@ -1717,28 +1827,11 @@ void rt_scene_destroy(rt_scene* s)
     for (float* p : s->texturePixels) (void)hipFree(p);
     (void)hipFree(s->d_textures);
     (void)hipFree(s->d_blob);
-    (void)hipFree(s->d_stats);
-    (void)hipFree(s->d_work);
     (void)hipFree(s->d_rgb);
     (void)hipFree(s->d_scratch);
     (void)hipFree(s->d_primId);
     (void)hipFree(s->d_primT);
-    (void)hipFree(s->d_accum);
-    (void)hipFree(s->d_nonfinite);
-    (void)hipFree(s->d_shadeQ);
-    (void)hipFree(s->d_leafQ);
-    (void)hipFree(s->d_states);
-    (void)hipFree(s->d_active[0]);
-    (void)hipFree(s->d_active[1]);
-    (void)hipFree(s->d_activeRay[0]);
-    (void)hipFree(s->d_activeRay[1]);
-    (void)hipFree(s->d_roundCounts);
-    (void)hipFree(s->d_pathRays[0]);
-    (void)hipFree(s->d_pathRays[1]);
-    (void)hipFree(s->d_hits);
-    (void)hipFree(s->d_shadowRays);
-    (void)hipFree(s->d_longList);
-    (void)hipFree(s->d_fallList);
+    for (Workspace* w : s->workspaces) free_workspace(w);
     delete s;
 }
 
@@ -1767,6 +1860,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         return RT_ERR_INVALID;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    RT_HIP(hipSetDevice(scene->device));
+    Workspace* const wsp = workspace_for(scene, st, true);
+    if (!wsp) return RT_ERR_HIP;
+    Workspace& w = *wsp;
     const int tilesX = (width + 7) / 8;
     const int tileRows = (height + 7) / 8;
     const int stripeTileRows = reg.stripeRows / 8;
@@ -1776,9 +1873,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const int myStripes = (stripes > reg.rank) ? (stripes - reg.rank + reg.world - 1) / reg.world : 0;
     const int myTileRows = myStripes * stripeTileRows;
     const uint32_t nWork = (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
-    RT_HIP(hipMemsetAsync(scene->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
-    RT_HIP(hipMemsetAsync(scene->d_work, 0, 256, st));
-    scene->lastWasWavefront = false;
+    RT_HIP(hipMemsetAsync(w.d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
+    RT_HIP(hipMemsetAsync(w.d_work, 0, 256, st));
+    w.lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
     const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
     const uint32_t fullGrid = (nWork + kBlock - 1) / kBlock;
@@ -1796,7 +1893,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         P.rank = reg.rank, P.world = reg.world;
         P.nWork = nWork;
         P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
-        P.stats = scene->d_stats, P.work = scene->d_work;
+        P.stats = w.d_stats, P.work = w.d_work;
         if (cull && !count) hipLaunchKernelGGL((render_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
         else if (cull && count) hipLaunchKernelGGL((render_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
         else if (!cull && !count) hipLaunchKernelGGL((render_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
@@ -1807,33 +1904,55 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
 
     // ---- wavefront pipeline ----
     const size_t px = (size_t)width * height;
-    if (px > scene->accumPixels) {
-        (void)hipFree(scene->d_accum), (void)hipFree(scene->d_nonfinite);
-        scene->d_accum = nullptr, scene->d_nonfinite = nullptr, scene->accumPixels = 0;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_accum), px * 3 * sizeof(long long)));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_nonfinite), px * sizeof(uint32_t)));
-        RT_HIP(hipMemset(scene->d_accum, 0, px * 3 * sizeof(long long)));
-        RT_HIP(hipMemset(scene->d_nonfinite, 0, px * sizeof(uint32_t)));
-        scene->accumPixels = px;
+    if (px > w.accumPixels) {
+        (void)hipFree(w.d_accum), (void)hipFree(w.d_nonfinite);
+        w.d_accum = nullptr, w.d_nonfinite = nullptr, w.accumPixels = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_accum), px * 3 * sizeof(long long)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_nonfinite), px * sizeof(uint32_t)));
+        RT_HIP(hipMemset(w.d_accum, 0, px * 3 * sizeof(long long)));
+        RT_HIP(hipMemset(w.d_nonfinite, 0, px * sizeof(uint32_t)));
+        w.accumPixels = px;
     }
     uint64_t want = (uint64_t)nWork * 8u;
     if (want < (1u << 20)) want = 1u << 20;
     if (want > kMaxQueueTasks) want = kMaxQueueTasks;
-    if (scene->shadeCap < want) {
-        (void)hipFree(scene->d_shadeQ);
-        scene->d_shadeQ = nullptr, scene->shadeCap = 0;
-        RT_HIP(hipMalloc(&scene->d_shadeQ, want * sizeof(ShadeTask)));
-        scene->shadeCap = (uint32_t)want;
+    if (w.shadeCap < want) {
+        (void)hipFree(w.d_shadeQ);
+        w.d_shadeQ = nullptr, w.shadeCap = 0;
+        RT_HIP(hipMalloc(&w.d_shadeQ, want * sizeof(ShadeTask)));
+        w.shadeCap = (uint32_t)want;
     }
-    if (scene->leafCap < want) {
-        (void)hipFree(scene->d_leafQ);
-        scene->d_leafQ = nullptr, scene->leafCap = 0;
-        RT_HIP(hipMalloc(&scene->d_leafQ, want * sizeof(LeafTask)));
-        scene->leafCap = (uint32_t)want;
+    if (w.leafCap < want) {
+        (void)hipFree(w.d_leafQ);
+        w.d_leafQ = nullptr, w.leafCap = 0;
+        RT_HIP(hipMalloc(&w.d_leafQ, want * sizeof(LeafTask)));
+        w.leafCap = (uint32_t)want;
     }
-    // a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
-    uint32_t batchRays = 0;
+    const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
+    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
+        && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
+    // The path stage - the rays whose outcome the pixel's sampler depends on - runs as one persistent launch in which a group
+    // of lanes owns a pixel from its first ray to its last (path_kernel), or, without it, in frame-wide rounds.
+    const bool usePathGroup = scene->pathMode == 1 && groupOk && cull && !count && (scene->groupLanes == 8 || scene->groupLanes == 16);
+    // Rounds a full recursion tree needs when its loops are walked one child per round (batched loops need fewer): beyond what
+    // the round-based stage accepts, the pixel-per-lane launch takes the frame, whose chains may be as long as they like.
+    bool longChains = false;
     {
+        const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? std::max(1u, features->numGlossySamples) : 1;
+        uint64_t links = 0, term = 1;
+        for (int l = startDepth; l <= RT_MAX_RAY_DEPTH && links < (1u << 24); l++) {
+            links += term, term *= fan;
+            if (!features->enableReflections) break;
+        }
+        const uint64_t ns = features->enableJitteredSampling ? (uint64_t)roundf(sqrtf((float)features->numPixelSamples)) : 0;
+        links *= std::max<uint64_t>(features->numPixelSamples, ns * ns);
+        longChains = links > kMaxRounds / 2;
+    }
+    const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count;
+    const bool usePath = usePathGroup || usePathLane;
+    // (rounds only) a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
+    uint32_t batchRays = 0;
+    if (!usePath) {
         bool area = false;
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
@@ -1842,27 +1961,27 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             batchRays = N * (N + 1) / 2;
     }
     const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
-    if (scene->stateCap < nWork) {
-        (void)hipFree(scene->d_states), (void)hipFree(scene->d_active[0]), (void)hipFree(scene->d_active[1]);
-        (void)hipFree(scene->d_activeRay[0]), (void)hipFree(scene->d_activeRay[1]);
-        scene->d_states = nullptr, scene->d_active[0] = scene->d_active[1] = nullptr, scene->stateCap = 0;
-        scene->d_activeRay[0] = scene->d_activeRay[1] = nullptr;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_states), (size_t)nWork * kStateDwords * sizeof(float)));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[0]), (size_t)nWork * sizeof(uint32_t)));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_active[1]), (size_t)nWork * sizeof(uint32_t)));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_activeRay[0]), (size_t)nWork * sizeof(uint32_t)));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_activeRay[1]), (size_t)nWork * sizeof(uint32_t)));
-        scene->stateCap = nWork;
+    if (w.stateCap < nWork) {
+        (void)hipFree(w.d_states), (void)hipFree(w.d_active[0]), (void)hipFree(w.d_active[1]);
+        (void)hipFree(w.d_activeRay[0]), (void)hipFree(w.d_activeRay[1]);
+        w.d_states = nullptr, w.d_active[0] = w.d_active[1] = nullptr, w.stateCap = 0;
+        w.d_activeRay[0] = w.d_activeRay[1] = nullptr;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_states), (size_t)nWork * kStateDwords * sizeof(float)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_active[0]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_active[1]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_activeRay[0]), (size_t)nWork * sizeof(uint32_t)));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_activeRay[1]), (size_t)nWork * sizeof(uint32_t)));
+        w.stateCap = nWork;
     }
-    if (scene->pathRayCap < pathRaysWanted) {
-        (void)hipFree(scene->d_pathRays[0]), (void)hipFree(scene->d_pathRays[1]);
-        scene->d_pathRays[0] = scene->d_pathRays[1] = nullptr, scene->pathRayCap = 0;
-        RT_HIP(hipMalloc(&scene->d_pathRays[0], pathRaysWanted * sizeof(RayRec)));
-        RT_HIP(hipMalloc(&scene->d_pathRays[1], pathRaysWanted * sizeof(RayRec)));
-        scene->pathRayCap = pathRaysWanted;
+    if (w.pathRayCap < pathRaysWanted) {
+        (void)hipFree(w.d_pathRays[0]), (void)hipFree(w.d_pathRays[1]);
+        w.d_pathRays[0] = w.d_pathRays[1] = nullptr, w.pathRayCap = 0;
+        RT_HIP(hipMalloc(&w.d_pathRays[0], pathRaysWanted * sizeof(RayRec)));
+        RT_HIP(hipMalloc(&w.d_pathRays[1], pathRaysWanted * sizeof(RayRec)));
+        w.pathRayCap = pathRaysWanted;
     }
     const size_t countWords = 2 * kMaxRounds + kMaxTraceLaunches;
-    if (!scene->d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_roundCounts), countWords * sizeof(uint32_t)));
+    if (!w.d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_roundCounts), countWords * sizeof(uint32_t)));
     // shadow rays: one per point light and numShadowSamples per area light for every shade task, generated and
     // traced in chunks of tasks that fit the shadow-ray buffer
     uint32_t raysPerTask = 0, lightDraws = 0;
@@ -1873,34 +1992,34 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         else if (ty == 2) lightDraws += 2 * features->numShadowSamples;
     }
     const bool shadows = features->enableShadows && raysPerTask > 0;
-    uint32_t chunkTasks = scene->shadeCap, nChunks = 1;
+    uint32_t chunkTasks = w.shadeCap, nChunks = 1;
     if (shadows) {
         if (raysPerTask > kMaxShadowRays) {
             rt::set_error("rt_render: %u shadow rays per hit exceed the limit of %llu", raysPerTask, (unsigned long long)kMaxShadowRays);
             return RT_ERR_LIMIT;
         }
-        uint64_t raysWanted = (uint64_t)scene->shadeCap * raysPerTask;
+        uint64_t raysWanted = (uint64_t)w.shadeCap * raysPerTask;
         if (raysWanted > kMaxShadowRays) raysWanted = kMaxShadowRays - (kMaxShadowRays % raysPerTask);
         chunkTasks = (uint32_t)(raysWanted / raysPerTask);
-        nChunks = (scene->shadeCap + chunkTasks - 1) / chunkTasks;
-        if (scene->shadowCap < raysWanted) {
-            (void)hipFree(scene->d_shadowRays);
-            scene->d_shadowRays = nullptr, scene->shadowCap = 0;
-            RT_HIP(hipMalloc(&scene->d_shadowRays, raysWanted * sizeof(RayRec)));
-            scene->shadowCap = raysWanted;
+        nChunks = (w.shadeCap + chunkTasks - 1) / chunkTasks;
+        if (w.shadowCap < raysWanted) {
+            (void)hipFree(w.d_shadowRays);
+            w.d_shadowRays = nullptr, w.shadowCap = 0;
+            RT_HIP(hipMalloc(&w.d_shadowRays, raysWanted * sizeof(RayRec)));
+            w.shadowCap = raysWanted;
         }
     }
     {
         size_t hitsWanted = pathRaysWanted;
-        if (hitsWanted < scene->leafCap) hitsWanted = scene->leafCap;
+        if (hitsWanted < w.leafCap) hitsWanted = w.leafCap;
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
-        if (scene->hitCap < hitsWanted) {
-            (void)hipFree(scene->d_hits), (void)hipFree(scene->d_longList), (void)hipFree(scene->d_fallList);
-            scene->d_hits = nullptr, scene->d_longList = nullptr, scene->d_fallList = nullptr, scene->hitCap = 0;
-            RT_HIP(hipMalloc(&scene->d_hits, hitsWanted * sizeof(HitRec)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_longList), hitsWanted * sizeof(uint32_t)));
-            RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_fallList), hitsWanted * sizeof(uint32_t)));
-            scene->hitCap = hitsWanted;
+        if (w.hitCap < hitsWanted) {
+            (void)hipFree(w.d_hits), (void)hipFree(w.d_longList), (void)hipFree(w.d_fallList);
+            w.d_hits = nullptr, w.d_longList = nullptr, w.d_fallList = nullptr, w.hitCap = 0;
+            RT_HIP(hipMalloc(&w.d_hits, hitsWanted * sizeof(HitRec)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_longList), hitsWanted * sizeof(uint32_t)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_fallList), hitsWanted * sizeof(uint32_t)));
+            w.hitCap = hitsWanted;
         }
     }
     // Rounds needed by a full tree: one ray per level of the sequential part, times the fan-out
@@ -1926,14 +2045,15 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         }
         chain *= nRays;
     }
+    if (usePath) chain = 0; // no rounds: a pixel's chain may be as long as it likes
     if (chain > kMaxRounds - 1 || 6 * nChunks + 32 > kMaxTraceLaunches - 6 * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
                       (unsigned long long)chain, kMaxRounds - 1, nChunks);
         return RT_ERR_LIMIT;
     }
-    RT_HIP(hipMemsetAsync(scene->d_roundCounts, 0, countWords * sizeof(uint32_t), st));
-    scene->fallSlots.clear();
+    RT_HIP(hipMemsetAsync(w.d_roundCounts, 0, countWords * sizeof(uint32_t), st));
+    w.fallSlots.clear();
     WaveParams P;
     P.S = scene->view;
     P.cam = *camera;
@@ -1943,18 +2063,18 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     P.rank = reg.rank, P.world = reg.world;
     P.nWork = nWork;
     P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
-    P.stats = scene->d_stats, P.work = scene->d_work;
-    P.accum = scene->d_accum, P.nonfinite = scene->d_nonfinite;
-    P.shadeQ = static_cast<ShadeTask*>(scene->d_shadeQ), P.leafQ = static_cast<LeafTask*>(scene->d_leafQ);
-    P.qCount = scene->d_work + 8;
-    P.shadeCap = scene->shadeCap, P.leafCap = scene->leafCap;
+    P.stats = w.d_stats, P.work = w.d_work;
+    P.accum = w.d_accum, P.nonfinite = w.d_nonfinite;
+    P.shadeQ = static_cast<ShadeTask*>(w.d_shadeQ), P.leafQ = static_cast<LeafTask*>(w.d_leafQ);
+    P.qCount = w.d_work + 8;
+    P.shadeCap = w.shadeCap, P.leafCap = w.leafCap;
     P.lightDraws = lightDraws;
-    P.states = scene->d_states;
-    P.pathRays = static_cast<RayRec*>(scene->d_pathRays[0]), P.pathRaysIn = nullptr;
-    P.rayCap = (uint32_t)(scene->pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : scene->pathRayCap);
+    P.states = w.d_states;
+    P.pathRays = static_cast<RayRec*>(w.d_pathRays[0]), P.pathRaysIn = nullptr;
+    P.rayCap = (uint32_t)(w.pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : w.pathRayCap);
     P.batchRays = batchRays;
-    P.hits = static_cast<const HitRec*>(scene->d_hits);
-    P.shadowRays = static_cast<RayRec*>(scene->d_shadowRays);
+    P.hits = static_cast<const HitRec*>(w.d_hits);
+    P.shadowRays = static_cast<RayRec*>(w.d_shadowRays);
     P.chunkBase = 0, P.chunkTasks = chunkTasks, P.raysPerTask = raysPerTask;
     const uint32_t taskGrid = (uint32_t)scene->numCUs * 8u;
     uint32_t resolveGrid = fullGrid < taskGrid ? fullGrid : taskGrid;
@@ -1968,16 +2088,16 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
         mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
     }
-    const bool planned = !count && key == scene->planKey && scene->roundRays.size() == rounds && !getenv("RT_AMD_NO_PLAN");
-    scene->lastKey = key, scene->lastRounds = rounds;
+    const bool planned = !count && key == w.planKey && w.roundRays.size() == rounds && !getenv("RT_AMD_NO_PLAN");
+    w.lastKey = key, w.lastRounds = usePath ? 0u : rounds;
 
     TraceParams T;
     T.S = scene->view;
-    T.hits = static_cast<HitRec*>(scene->d_hits);
-    T.stats = scene->d_stats;
+    T.hits = static_cast<HitRec*>(w.d_hits);
+    T.stats = w.d_stats;
     T.useBvh = features->enableAccelStructure ? 1u : 0u;
     uint32_t nextFetch = 2 * kMaxRounds;
-    uint32_t* const rayCounts = scene->d_roundCounts + kMaxRounds;
+    uint32_t* const rayCounts = w.d_roundCounts + kMaxRounds;
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
     const uint32_t traceGrid = (uint32_t)scene->numCUs * scene->laneBlocksPerCU;
@@ -1988,10 +2108,14 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     uint32_t gridNow = groupGrid; // workgroups of the next group launch: fewer where few rays are expected (the rest is fetched in chunks)
     auto launch_one = [&](uint32_t groupLanes, bool query) {
-        T.fetch = scene->d_roundCounts + nextFetch++;
+        T.fetch = w.d_roundCounts + nextFetch++;
         T.S = query ? scene->queryView : scene->view;
         if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
+            if (groupLanes >= 8 && scene->quadTrace && scene->queryView.quadNodes) { // four lanes per ray instead
+                hipLaunchKernelGGL(quad_trace_kernel, dim3(std::max(1u, gridNow * 4u / groupLanes)), dim3(kBlock), 0, st, T);
+                return;
+            }
             if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
             else if (groupLanes == 16)
                 hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
@@ -2024,23 +2148,20 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // known on the device, so every variant is launched and those whose range does not hold the count return at once.
     // With a query tree the rays walk that tree first; the few whose result is not provably the reference's are
     // traced again in the reference's tree.
-    const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
-    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
-        && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul, bool smallRound = false,
                             uint32_t expected = 0) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
-        T.indirect = nullptr, T.stepBudget = 0, T.longList = scene->d_longList, T.longCount = nullptr;
-        T.fallList = scene->d_fallList, T.fallCount = nullptr;
+        T.indirect = nullptr, T.stepBudget = 0, T.longList = w.d_longList, T.longCount = nullptr;
+        T.fallList = w.d_fallList, T.fallCount = nullptr;
         T.runLo = 0, T.runHi = 0xffffffffu;
         if (!groupOk) {
             launch_one(1, false);
             return;
         }
-        uint32_t* longCount = scene->d_roundCounts + nextFetch++;
-        if (useQuery) scene->fallSlots.push_back(nextFetch);
-        uint32_t* fallCount = scene->d_roundCounts + nextFetch++;
+        uint32_t* longCount = w.d_roundCounts + nextFetch++;
+        if (useQuery) w.fallSlots.push_back(nextFetch);
+        uint32_t* fallCount = w.d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
         T.runLo = scene->laneModeAbove;
         const uint32_t budget = (count || smallRound) ? 0u : (useQuery ? scene->queryStepBudget : scene->stepBudget);
@@ -2055,13 +2176,13 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         gridNow = groupGrid;
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
-            T.indirect = scene->d_longList;
+            T.indirect = w.d_longList;
             T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
             launch_one(scene->groupLanes, useQuery);
         }
         if (useQuery) { // the unsettled rays, in the reference's tree
             T.runLo = 0, T.runHi = 0xffffffffu;
-            T.indirect = scene->d_fallList;
+            T.indirect = w.d_fallList;
             T.countPtr = fallCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
             gridNow = std::min(groupGrid, 256u); // a handful of rays as a rule
             launch_one(scene->groupLanes, false);
@@ -2070,33 +2191,134 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     };
 
     P.activeIn = nullptr, P.activeInCount = nullptr;
-    P.activeOut = scene->d_active[0], P.activeOutCount = scene->d_roundCounts;
-    P.activeRayIn = nullptr, P.activeRayOut = scene->d_activeRay[0], P.rayCountOut = rayCounts;
+    P.activeOut = w.d_active[0], P.activeOutCount = w.d_roundCounts;
+    P.activeRayIn = nullptr, P.activeRayOut = w.d_activeRay[0], P.rayCountOut = rayCounts;
     hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
-    for (uint32_t r = 1; r <= rounds; r++) {
+    if (usePathLane) {
+        PathKParams K;
+        const uint32_t N = features->numGlossySamples ? features->numGlossySamples : 1u;
+        K.shadeChunk = 256u, K.leafChunk = N * 64u;
+        K.advanceAt = scene->advanceAt, K.advanceEvery = scene->advanceEvery;
+        K.scatter = getenv("RT_AMD_SCATTER") ? 1u : 0u;
+        K.contList = nullptr, K.contCount = nullptr, K.linkBudget = 0, K.minLanes = 0;
+        const uint32_t pathGrid = (uint32_t)scene->numCUs * scene->pathBlocksPerCU;
+        const bool query = features->enableAccelStructure && scene->queryView.cert != nullptr && !(flags & RT_RENDER_REFERENCE_TREE);
+        const uint32_t suspSlot = nextFetch++;
+        K.T = query ? scene->queryView : scene->view;
+        K.list = nullptr, K.countPtr = w.d_roundCounts; // the camera kernel's states, one per pixel with a ray to trace
+        K.fetch = w.d_roundCounts + nextFetch++;
+        K.suspList = query ? w.d_fallList : nullptr, K.suspCount = query ? w.d_roundCounts + suspSlot : nullptr;
+        K.reserve = 0;
+        K.dbg = nullptr;
+#ifdef RT_PATH_PROFILE
+        K.dbg = reinterpret_cast<unsigned long long*>(w.d_activeRay[1]);
+        (void)hipMemsetAsync(K.dbg, 0, 16 * 4 * pathGrid, st);
+        w.dbgWaves = 4 * pathGrid;
+#endif
+        uint32_t grid = pathGrid;
+        auto launch_ref = [&]() {
+            if (stackClass == 0) hipLaunchKernelGGL((lane_path_kernel<16, false>), dim3(grid), dim3(kBlock), 0, st, P, K);
+            else if (stackClass == 1) hipLaunchKernelGGL((lane_path_kernel<24, false>), dim3(grid), dim3(kBlock), 0, st, P, K);
+            else hipLaunchKernelGGL((lane_path_kernel<32, false>), dim3(grid), dim3(kBlock), 0, st, P, K);
+        };
+        // slices: every launch but the last sets unfinished pixels aside after linkBudget rays (or when its wave runs thin)
+        // and the next one packs them into full waves again; the last launch walks what is left to its end
+        uint64_t chainLinks = 1;
+        {
+            const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? std::max(1u, features->numGlossySamples) : 1;
+            uint64_t term = 1;
+            chainLinks = 0;
+            for (int l = startDepth; l <= RT_MAX_RAY_DEPTH && chainLinks < (1u << 20); l++) {
+                chainLinks += term;
+                term *= fan;
+                if (!features->enableReflections) break;
+            }
+            chainLinks *= std::max<uint64_t>(1, features->numPixelSamples) + 3; // jittered sampling rounds the sample count up
+        }
+        const uint32_t linkBudget = std::max<uint32_t>(scene->linkBudget, (uint32_t)(chainLinks / 48u) + 1u);
+        const uint32_t slices = scene->linkBudget ? (uint32_t)std::min<uint64_t>(chainLinks / linkBudget + 2u, 64u) : 1u;
+        K.linkBudget = linkBudget, K.minLanes = scene->minLanes;
+        const int quads = (query && scene->queryView.quadNodes) ? scene->pathQuads : 0;
+        for (uint32_t sl = 0; sl < slices; sl++) {
+            const bool last = sl + 1 == slices;
+            const uint32_t contSlot = nextFetch++;
+            if (sl == 0) w.sliceSlots.clear();
+            w.sliceSlots.push_back(contSlot);
+            K.contList = last ? nullptr : w.d_active[(sl + 1) & 1], K.contCount = last ? nullptr : w.d_roundCounts + contSlot;
+            K.fetch = w.d_roundCounts + nextFetch++;
+            if (!query) launch_ref();
+            else if (quads == 1) hipLaunchKernelGGL((quad_path_kernel<true>), dim3(grid), dim3(kBlock), 0, st, P, K);
+            else if (quads == 2) hipLaunchKernelGGL((quad_path_kernel<false>), dim3(grid), dim3(kBlock), 0, st, P, K);
+            else hipLaunchKernelGGL((lane_path_kernel<16, true>), dim3(grid), dim3(kBlock), 0, st, P, K);
+            K.list = w.d_active[(sl + 1) & 1], K.countPtr = w.d_roundCounts + contSlot;
+        }
+        if (query) {
+            // the pixels that met a ray the query tree could not answer with proof go on in the reference's tree
+            w.fallSlots.push_back(suspSlot);
+            K.T = scene->view;
+            K.list = w.d_fallList, K.countPtr = w.d_roundCounts + suspSlot;
+            K.fetch = w.d_roundCounts + nextFetch++;
+            K.suspList = nullptr, K.suspCount = nullptr, K.contList = nullptr, K.contCount = nullptr;
+            grid = std::min(pathGrid, 256u); // a handful of pixels as a rule; any number is walked
+            launch_ref();
+        }
+    } else if (usePathGroup) {
+        PathKParams K;
+        K.advanceAt = K.advanceEvery = 0;
+        K.dbg = nullptr, K.scatter = 0;
+        K.contList = nullptr, K.contCount = nullptr, K.linkBudget = 0, K.minLanes = 0;
+        const uint32_t N = features->numGlossySamples ? features->numGlossySamples : 1u;
+        K.shadeChunk = 128u, K.leafChunk = N * 32u;
+        const uint32_t pathGrid = (uint32_t)scene->numCUs * scene->pathBlocksPerCU;
+        const uint32_t suspSlot = nextFetch++;
+        K.T = useQuery ? scene->queryView : scene->view;
+        K.list = nullptr, K.countPtr = w.d_roundCounts; // the camera kernel's states, one per pixel with a ray to trace
+        K.fetch = w.d_roundCounts + nextFetch++;
+        K.suspList = useQuery ? w.d_fallList : nullptr, K.suspCount = useQuery ? w.d_roundCounts + suspSlot : nullptr;
+        K.reserve = (int)(useQuery ? scene->queryDepth : scene->treeDepth) + 2;
+        const bool wide = scene->groupLanes == 16;
+        if (useQuery) {
+            if (wide) hipLaunchKernelGGL((path_kernel<16, true>), dim3(pathGrid), dim3(kBlock), 0, st, P, K);
+            else hipLaunchKernelGGL((path_kernel<8, true>), dim3(pathGrid), dim3(kBlock), 0, st, P, K);
+            // the pixels that met a ray the query tree could not answer with proof go on in the reference's tree
+            w.fallSlots.push_back(suspSlot);
+            K.T = scene->view;
+            K.list = w.d_fallList, K.countPtr = w.d_roundCounts + suspSlot;
+            K.fetch = w.d_roundCounts + nextFetch++;
+            K.suspList = nullptr, K.suspCount = nullptr;
+            K.reserve = (int)scene->treeDepth + 2;
+            const uint32_t grid2 = std::min(pathGrid, 256u); // a handful of pixels as a rule; any number is walked
+            if (wide) hipLaunchKernelGGL((path_kernel<16, false>), dim3(grid2), dim3(kBlock), 0, st, P, K);
+            else hipLaunchKernelGGL((path_kernel<8, false>), dim3(grid2), dim3(kBlock), 0, st, P, K);
+        } else {
+            if (wide) hipLaunchKernelGGL((path_kernel<16, false>), dim3(pathGrid), dim3(kBlock), 0, st, P, K);
+            else hipLaunchKernelGGL((path_kernel<8, false>), dim3(pathGrid), dim3(kBlock), 0, st, P, K);
+        }
+    }
+    for (uint32_t r = 1; r <= rounds && !usePath; r++) {
         // the camera kernel emits exactly one ray per active state and counts them once
         // a round counts as small when the plan's frame would have sent it to the group kernel (which is about as fast as the
         // other schedule up to half as many rays again, should this frame's round be larger)
-        const bool smallRound = planned && scene->roundRays[r - 1] < scene->laneModeAbove;
-        launch_trace(scene->d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? scene->d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
-                     smallRound ? scene->roundRays[r - 1] : 0u);
-        P.pathRaysIn = static_cast<const RayRec*>(scene->d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(scene->d_pathRays[r & 1]);
-        P.activeIn = scene->d_active[(r - 1) & 1], P.activeInCount = scene->d_roundCounts + (r - 1);
-        P.activeOut = scene->d_active[r & 1], P.activeOutCount = scene->d_roundCounts + r;
-        P.activeRayIn = scene->d_activeRay[(r - 1) & 1], P.activeRayOut = scene->d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
+        const bool smallRound = planned && w.roundRays[r - 1] < scene->laneModeAbove;
+        launch_trace(w.d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? w.d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
+                     smallRound ? w.roundRays[r - 1] : 0u);
+        P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);
+        P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
+        P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
+        P.activeRayIn = w.d_activeRay[(r - 1) & 1], P.activeRayOut = w.d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
         hipLaunchKernelGGL(path_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     }
     // what the batched loops left for later: their children's hit records and the grandchildren's rays
     if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-    launch_trace(scene->d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, scene->leafCap, 1);
+    launch_trace(w.d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, w.leafCap, 1);
     hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     for (uint32_t c = 0; c < nChunks; c++) {
         P.chunkBase = c * chunkTasks;
-        P.chunkTasks = (scene->shadeCap - P.chunkBase < chunkTasks) ? scene->shadeCap - P.chunkBase : chunkTasks;
+        P.chunkTasks = (w.shadeCap - P.chunkBase < chunkTasks) ? w.shadeCap - P.chunkBase : chunkTasks;
         if (shadows) {
             hipLaunchKernelGGL(shadow_gen_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-            launch_trace(scene->d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
-            P.hits = static_cast<const HitRec*>(scene->d_hits);
+            launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
+            P.hits = static_cast<const HitRec*>(w.d_hits);
         } else {
             P.hits = nullptr;
         }
@@ -2104,7 +2326,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     hipLaunchKernelGGL(resolve_kernel, dim3(resolveGrid), dim3(kBlock), 0, st, P);
     RT_HIP(hipGetLastError());
-    scene->lastWasWavefront = true;
+    w.lastWasWavefront = true;
     return RT_OK;
 }
 
@@ -2181,29 +2403,63 @@ int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, fl
     return rt_bloom(d_rgb, scratch, width, height, filterSize, threshold, intensity, nullptr, stream);
 }
 
-int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
+// What rt_sync reports for the last frame queued with the buffers `w` (whose stream has been waited for): its counters,
+// and whether it is complete.  Also notes the frame's round sizes for the next frame's launch plan.
+static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
 {
-    if (!scene) {
-        rt::set_error("rt_sync: null scene");
-        return RT_ERR_INVALID;
-    }
-    RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    (void)scene;
     unsigned long long h[S_COUNT] = {};
     {
         unsigned long long all[kStatCopies * kStatStride];
-        RT_HIP(hipMemcpy(all, scene->d_stats, sizeof(all), hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(all, w.d_stats, sizeof(all), hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < kStatCopies; c++)
             for (int i = 0; i < S_COUNT; i++) h[i] += all[c * kStatStride + i];
     }
+#ifdef RT_PATH_PROFILE
+    {
+        unsigned long long all[kStatCopies * kStatStride];
+        RT_HIP(hipMemcpy(all, w.d_stats, sizeof(all), hipMemcpyDeviceToHost));
+        fprintf(stderr, "path_kernel slowest wave: total %llu cycles, fetch %llu, advance %llu, begin %llu, steps %llu; iterations %llu, advances %llu, step iterations %llu\n",
+                all[16], all[17], all[18], all[19], all[20], all[21], all[22], all[23]);
+        fprintf(stderr, "path_kernel: longest pixel chain %llu rays, longest ray %llu steps, %llu rays, %llu steps in all\n", all[24], all[25], all[26], all[27]);
+        fprintf(stderr, "path_kernel: %llu waves, mean wave time %llu cycles, mean step iterations per wave %llu\n", all[29], all[28] / (all[29] ? all[29] : 1), all[30] / (all[29] ? all[29] : 1));
+        if (w.dbgWaves) {
+            std::vector<unsigned long long> tv(2 * w.dbgWaves);
+            RT_HIP(hipMemcpy(tv.data(), w.d_activeRay[1], tv.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> us;
+            unsigned long long start = ~0ull;
+            for (uint32_t i = 0; i < w.dbgWaves; i++) if (tv[2 * i]) start = std::min(start, tv[2 * i]);
+            std::vector<double> st_, du;
+            for (uint32_t i = 0; i < w.dbgWaves; i++)
+                if (tv[2 * i + 1]) us.push_back((double)(tv[2 * i + 1] - start)), st_.push_back((double)(tv[2 * i] - start)), du.push_back((double)(tv[2 * i + 1] - tv[2 * i]));
+            std::sort(us.begin(), us.end()), std::sort(st_.begin(), st_.end()), std::sort(du.begin(), du.end());
+            if (!us.empty()) {
+                const double unit = 100.0 / us.back(); // percent of the kernel's duration
+                const char* names[3] = { "end", "start", "duration" };
+                std::vector<double>* vs[3] = { &us, &st_, &du };
+                for (int k = 0; k < 3; k++) {
+                    fprintf(stderr, "path_kernel: wave %s (%% of the launch), percentiles 10 25 50 75 90 95 99 100:", names[k]);
+                    for (double q : { 0.10, 0.25, 0.50, 0.75, 0.90, 0.95, 0.99, 1.0 }) fprintf(stderr, " %.1f", unit * (*vs[k])[std::min(vs[k]->size() - 1, (size_t)(q * vs[k]->size()))]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+        fprintf(stderr, "path_kernel: pixels by chain length (bins of 4 rays):");
+        for (int b = 0; b < 23; b++) fprintf(stderr, " %llu", all[32 + 9 + b]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "path_kernel: lanes per step iteration %.1f, advances %llu with %.1f lanes each; mean advance cycles %llu per wave, mean step cycles %llu per wave\n",
+                (double)all[31] / (double)(all[30] ? all[30] : 1), all[15], (double)all[14] / (double)(all[15] ? all[15] : 1), all[13] / (all[29] ? all[29] : 1), all[12] / (all[29] ? all[29] : 1));
+    }
+#endif
     if (stats) {
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
         stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
         stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;
-        if (scene->lastWasWavefront && !scene->fallSlots.empty()) {
-            const uint32_t lo = scene->fallSlots.front(), hi = scene->fallSlots.back();
+        if (w.lastWasWavefront && !w.fallSlots.empty()) {
+            const uint32_t lo = w.fallSlots.front(), hi = w.fallSlots.back();
             std::vector<uint32_t> c(hi - lo + 1);
-            RT_HIP(hipMemcpy(c.data(), scene->d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            for (uint32_t slot : scene->fallSlots) stats->referenceTreeQueries += c[slot - lo];
+            RT_HIP(hipMemcpy(c.data(), w.d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t slot : w.fallSlots) stats->referenceTreeQueries += c[slot - lo];
         }
     }
     if (h[S_OVERFLOW]) {
@@ -2220,40 +2476,70 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
                       "with RT_RENDER_SERIAL", h[S_BIGVALUE]);
         return RT_ERR_LIMIT;
     }
-    if (scene->lastWasWavefront && scene->lastRounds) { // a pixel still had rays to trace when the rounds ended
+    if (w.lastWasWavefront && w.lastRounds) { // a pixel still had rays to trace when the rounds ended
         uint32_t left = 0;
-        RT_HIP(hipMemcpy(&left, scene->d_roundCounts + scene->lastRounds, sizeof(left), hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(&left, w.d_roundCounts + w.lastRounds, sizeof(left), hipMemcpyDeviceToHost));
         if (left) {
             rt::set_error("%u pixels were unfinished after the frame's %u path rounds: the frame is incomplete; render with RT_RENDER_SERIAL",
-                          left, scene->lastRounds);
+                          left, w.lastRounds);
             return RT_ERR_LIMIT;
         }
     }
-    if (scene->lastWasWavefront && scene->lastRounds) { // the next frame's plan
-        const uint32_t n = scene->lastRounds;
-        scene->roundRays.assign(n, 0u);
-        RT_HIP(hipMemcpy(&scene->roundRays[0], scene->d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
-        if (n > 1) RT_HIP(hipMemcpy(&scene->roundRays[1], scene->d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        scene->planKey = scene->lastKey;
+    if (w.lastWasWavefront && !w.sliceSlots.empty() && getenv("RT_AMD_VERBOSE")) {
+        fprintf(stderr, "rt_amd: pixels set aside by the slices of the path stage:");
+        for (uint32_t slot : w.sliceSlots) {
+            uint32_t v = 0;
+            RT_HIP(hipMemcpy(&v, w.d_roundCounts + slot, sizeof(v), hipMemcpyDeviceToHost));
+            fprintf(stderr, " %u", v);
+        }
+        fprintf(stderr, "\n");
+    }
+    if (w.lastWasWavefront && w.lastRounds) { // the next frame's plan
+        const uint32_t n = w.lastRounds;
+        w.roundRays.assign(n, 0u);
+        RT_HIP(hipMemcpy(&w.roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
+        if (n > 1) RT_HIP(hipMemcpy(&w.roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        w.planKey = w.lastKey;
         if (getenv("RT_AMD_VERBOSE")) { // rays traced by the path rounds (candidate batches included), round by round
             unsigned long long sum = 0;
-            for (uint32_t v : scene->roundRays) sum += v;
+            for (uint32_t v : w.roundRays) sum += v;
             fprintf(stderr, "rt_amd: %u path rounds traced %llu rays:", n, sum);
-            for (uint32_t v : scene->roundRays) fprintf(stderr, " %u", v);
+            for (uint32_t v : w.roundRays) fprintf(stderr, " %u", v);
             fprintf(stderr, "\n");
         }
     }
-    if (scene->lastWasWavefront) { // did every deferred task fit its queue?
+    if (w.lastWasWavefront) { // did every deferred task fit its queue?
         uint32_t q[2];
-        RT_HIP(hipMemcpy(q, scene->d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
-        if (q[0] > scene->shadeCap || q[1] > scene->leafCap) {
+        RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
+        if (q[0] > w.shadeCap || q[1] > w.leafCap) {
             rt::set_error("task queues overflowed (%u shade tasks for %u slots, %u leaf tasks for %u slots): the frame is "
                           "incomplete; render with RT_RENDER_SERIAL or in smaller regions",
-                          q[0], scene->shadeCap, q[1], scene->leafCap);
+                          q[0], w.shadeCap, q[1], w.leafCap);
             return RT_ERR_LIMIT;
         }
     }
     return RT_OK;
+}
+
+int rt_sync(rt_scene* scene, void* stream, rt_stats* stats)
+{
+    if (!scene) {
+        rt::set_error("rt_sync: null scene");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    Workspace* const wsp = workspace_for(scene, static_cast<hipStream_t>(stream), false);
+    if (!wsp) { // no frame on this stream, or its buffers have gone to another stream since: what was noted then
+        if (stats) memset(stats, 0, sizeof(*stats));
+        for (const RetiredFrame& r : scene->retired)
+            if (r.stream == static_cast<hipStream_t>(stream)) {
+                if (stats) *stats = r.stats;
+                if (r.status != RT_OK) rt::set_error("%s", r.message.c_str());
+                return r.status;
+            }
+        return RT_OK;
+    }
+    return collect_frame(scene, *wsp, stats);
 }
 
 int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height, int startDepth,
@@ -2286,7 +2572,7 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
         if (rc != RT_OK) return rc;
     }
     rc = rt_sync(scene, nullptr, stats);
-    if (rc == RT_ERR_LIMIT && scene->lastWasWavefront) // queues too small for this frame: evaluate it depth-first instead
+    if (rc == RT_ERR_LIMIT && !(flags & RT_RENDER_SERIAL)) // queues too small for this frame: evaluate it depth-first instead
         return rt_render_image(scene, camera, features, width, height, startDepth, flags | RT_RENDER_SERIAL, rgb, primId, primT, stats);
     if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpy(rgb, scene->d_rgb, px * 12, hipMemcpyDeviceToHost));

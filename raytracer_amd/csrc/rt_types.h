@@ -76,6 +76,26 @@ struct Node4 {
 };
 static_assert(sizeof(Node4) == 128, "Node4 layout");
 
+// The query tree's 4-wide form for kernels that give a ray four lanes: one 32-byte record per child, so lane k of a
+// quad fetches child k with two 16-byte loads and the quad reads one 128-byte line.  A leaf reference holds the index
+// of a QuadLeaf instead of a first triangle.
+struct QuadChild {
+    float lo[3], hi[3];
+    uint32_t ref, pad;
+};
+struct QuadNode {
+    QuadChild c[4];
+};
+static_assert(sizeof(QuadNode) == 128, "QuadNode layout");
+// The up to four triangles of one query-tree leaf, interleaved so that lane k's j-th 16-byte load of its triangle k
+// lies next to the other lanes' (one 64-byte run per load and quad): plane[k], then edge words e[j][k].  Word e[4][k].z
+// holds the triangle's index in query-tree order (TriCert).  Unused slots hold zeros (their plane test yields NaN).
+struct QuadLeaf {
+    float plane[4][4];
+    float e[5][4][4];
+};
+static_assert(sizeof(QuadLeaf) == 384, "QuadLeaf layout");
+
 // Per triangle of the query tree (see QueryTree): where the triangle sits in the reference's tree.
 struct TriCert { // 32 B, read once per ray for the closest triangle found
     float leafLo[3];  // box of the reference leaf that holds the triangle
@@ -120,6 +140,8 @@ struct SceneView {
     uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
     const TriCert* cert; // null in the reference-order view; per query-tree triangle otherwise
     const Node4* nodes4; // query view: the query tree with four children per node, root = node 0 (`pairs` holds its binary form)
+    const QuadNode* quadNodes; // query view: the same nodes, one record per child (null when a leaf holds more than four triangles)
+    const QuadLeaf* quadLeaves;
     const NodePair* refPairs; // the reference's tree in either view
     uint32_t refRootRef;
     uint32_t fastBounds; // every box coordinate is 0 or has magnitude in [2^-60, 2^30]: reciprocal-based slab distances are exact
@@ -148,6 +170,8 @@ struct FlatScene {
 struct QueryTree {
     std::vector<NodePair> pairs; // the tree as built (two children per node): launches with several lanes per ray
     std::vector<Node4> nodes;    // the same tree with up to four children per node: one ray per lane
+    std::vector<QuadNode> quadNodes;   // ... and in the layout for four lanes per ray (empty when a leaf holds more than four triangles)
+    std::vector<QuadLeaf> quadLeaves;
     uint32_t pairRootRef = 0, pairDepth = 0;
     std::vector<TriPlane> triPlane; // copies in query-tree leaf order
     std::vector<TriEdges> triEdges;

@@ -295,6 +295,29 @@ def test_striped_regions_tile_the_frame():
     assert np.array_equal(got.view(np.uint32), full["rgb"].view(np.uint32))
 
 
+def test_frames_on_several_streams_overlap_without_mixing():
+    """Frames of one scene queued on different streams run on buffers of their own: five cameras on five streams at once
+    (more streams than the scene keeps buffer sets, so one set is taken over) give the frames and ray counts of the same
+    five renders done one after the other."""
+    torch = pytest.importorskip("torch")
+    g, _, _ = scene_pair("knot")
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)
+    W, H = 320, 184
+    cams = [both_cameras(W, H, dist=2.0 + 0.3 * k, rot_deg=(20.0, 20.0 + 40.0 * k, 0.0))[0] for k in range(5)]
+    want = [g.render_image(c, fg, W, H, start_depth=2, want_ids=False) for c in cams]
+    streams = [torch.cuda.Stream() for _ in cams]
+    bufs = [torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    for rep in range(2):  # the second pass runs with every stream's launch plan in place
+        for c, st, b in zip(cams, streams, bufs):
+            g.render_device(c, fg, W, H, 2, b.data_ptr(), stream=st.cuda_stream)
+        for k, (st, b) in enumerate(zip(streams, bufs)):
+            stats = g.sync(st.cuda_stream)
+            assert np.array_equal(b.cpu().numpy().view(np.uint32), want[k]["rgb"].view(np.uint32)), f"stream {k}, pass {rep}"
+            assert stats.rays == want[k]["stats"].rays
+    assert len({w["stats"].rays for w in want}) > 1  # the frames do differ
+
+
 def test_wavefront_matches_serial_and_is_reproducible():
     """The default pipeline (deferred shadow / last-level rays, fixed-point pixel sums) against the depth-first
     kernel that sums in the reference's nested order; and two runs of it bit for bit."""
@@ -396,11 +419,17 @@ def test_unnested_caller_tree_is_walked_as_given():
 
 @pytest.mark.parametrize("knobs", [dict(RT_AMD_T1="1"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET="2"), dict(RT_AMD_T1="1", RT_AMD_BUDGET="4", RT_AMD_NO_QUERY_TREE="1"),
                                    dict(RT_AMD_T1="4096"), dict(RT_AMD_GROUP_LANES="16"), dict(RT_AMD_GROUP_LANES="4"), dict(RT_AMD_GROUP_LANES="32"),
-                                   dict(RT_AMD_GROUP_LANES="1"), dict(RT_AMD_NO_BATCH="1"), dict(RT_AMD_QLEAF="2"), dict(RT_AMD_TRACE_BLOCKS="1", RT_AMD_T1="1")])
+                                   dict(RT_AMD_GROUP_LANES="1"), dict(RT_AMD_NO_BATCH="1"), dict(RT_AMD_QLEAF="2"), dict(RT_AMD_TRACE_BLOCKS="1", RT_AMD_T1="1"),
+                                   # the path stage as persistent launches instead of rounds: a group of lanes, one lane, four lanes per pixel
+                                   dict(RT_AMD_PATH_MODE="1"), dict(RT_AMD_PATH_MODE="1", RT_AMD_GROUP_LANES="16"), dict(RT_AMD_PATH_MODE="2"),
+                                   dict(RT_AMD_PATH_MODE="2", RT_AMD_NO_QUERY_TREE="1"), dict(RT_AMD_PATH_MODE="2", RT_AMD_SCATTER="1"),
+                                   dict(RT_AMD_PATH_MODE="2", RT_AMD_LINK_BUDGET="3", RT_AMD_MIN_LANES="48"), dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="1"),
+                                   dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="2", RT_AMD_ADVANCE_AT="4"), dict(RT_AMD_QUAD_TRACE="1")])
 def test_tuning_knobs_change_nothing(knobs, monkeypatch):
     """Every schedule the tuning knobs select (one ray per lane with rays handed over after a few steps, other group
-    widths, no candidate batches, another query tree) renders the frame of the default schedule bit for bit: small
-    scenes never reach the ray counts at which the default switches schedules by itself."""
+    widths, no candidate batches, another query tree, the path stage as one persistent launch per pixel group, lane or
+    quad instead of frame-wide rounds) renders the frame of the default schedule bit for bit: small scenes never reach
+    the ray counts at which the default switches schedules by itself."""
     _, _, sc = scene_pair("knot")
     W, H = 320, 180
     fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)
