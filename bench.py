@@ -4,14 +4,16 @@
   python bench.py --gpus N --steps K --warmup W            (N = 1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one frame: rt_render (+ RCCL all-gather of the row stripes when N > 1) + rt_bloom, with the
-scene and the framebuffer resident in HBM.  The frame is cut into interleaved 8-row stripes, stripe s
-belongs to rank s % N; every rank ends each step holding the full post-bloom frame.  Rank 0 prints one
-JSON line.  `value` counts every closest-hit query that contributes to the image (primary + shadow +
-reflection rays) over all ranks, divided by the slowest rank's time for the K steps.
+A step = one frame, as the reference's renderImage delivers it: rt_render (+ all-gather of the row stripes when
+N > 1) + rt_bloom + the copy of the finished frame into a pinned host buffer.  The scene is resident in HBM.  Frames are
+independent, so up to `--frames-in-flight` of them are queued on streams of their own and overlap on the GPU (the path
+stage of one frame is a chain of short dependent launches that leaves most of the chip idle); `ms_per_step` is the
+elapsed time of the K steps divided by K, `ms_per_frame_alone` what one frame takes with nothing else queued.  With
+N > 1 the frame is cut into interleaved 8-row stripes, stripe s belongs to rank s % N, and every rank ends each step
+holding the full post-bloom frame.  Rank 0 prints one JSON line.  `value` counts every closest-hit query that
+contributes to the image (primary + shadow + reflection rays) over all ranks, divided by the slowest rank's time.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -30,6 +32,10 @@ FEATURE_BASE = dict(enableShading=1, enableShadows=1, enableReflections=1, enabl
 WORKLOADS = {
     "dragon_glossy_bloom": dict(scene="dragon", feat=dict(enableGlossyReflection=1, numGlossySamples=4, enableBloomEffect=1),
                                 start_depth=2, desc="dragon stand-in (87,000 tris) 1080p, Phong + shadows, glossy x4, 4 bounces, bloom F=15"),
+    "dragon_glossy1_bloom": dict(scene="dragon", feat=dict(enableGlossyReflection=1, numGlossySamples=1, enableBloomEffect=1),
+                                 start_depth=2, desc="dragon stand-in 1080p, Phong + shadows, glossy x1, 4 bounces, bloom F=15"),
+    "dragon_glossy16_bloom": dict(scene="dragon", feat=dict(enableGlossyReflection=1, numGlossySamples=16, enableBloomEffect=1),
+                                  start_depth=2, desc="dragon stand-in 1080p, Phong + shadows, glossy x16, 4 bounces, bloom F=15"),
     "dragon_primary_shadow": dict(scene="dragon", feat=dict(enableReflections=0), start_depth=0,
                                   desc="dragon stand-in 1080p, primary + shadow rays"),
     "teapot_monkey_phong": dict(scene="teapot+monkey", feat=dict(), start_depth=2,
@@ -53,9 +59,20 @@ def build_scene_arrays(name, obj=None):
     return scenes.preset(name)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sc, feat_kw, start_depth, W, H, budget_s):
     """Times the CPU oracle (a port of the reference algorithm incl. its unused glossy debug query) on a
-    bounded, evenly spread sample of rows of the same frame, on this host's cores."""
+    bounded, evenly spread sample of rows of the same frame: on all of this host's cores the harness may use
+    (OMP_NUM_THREADS, else the CPU count) for three quarters of the budget, then on one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     kw = dict(FEATURE_BASE)
@@ -63,38 +80,47 @@ def cpu_baseline(sc, feat_kw, start_depth, W, H, budget_s):
     f = O.make_features(glossyDebugRay=1, **kw)
     cam = O.make_camera(W, H)
     s = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    t0 = time.perf_counter()
-    probe = s.render(cam, f, W, H, start_depth=start_depth, want_ids=False, threads=threads, row_step=32)
-    tp = time.perf_counter() - t0
-    step = 1
-    while tp * 32 / step > budget_s and step < 32:
-        step *= 2
-    # a sample of about budget_s seconds: every step-th row of the frame, repeated while time remains
-    reps, dt, r = 0, 0.0, probe
-    while reps == 0 or (dt + dt / reps <= budget_s and reps < 64):
+
+    def timed(threads, budget):
         t0 = time.perf_counter()
-        r = s.render(cam, f, W, H, start_depth=start_depth, want_ids=False, threads=threads, row_step=step)
-        dt += time.perf_counter() - t0
-        reps += 1
-    st = r["stats"]
-    rays = st["primary"] + st["shadow"] + st["secondary"]
-    return dict(value=rays * reps / dt / 1e6, unit="Mrays/s", cores=threads, kind="port",
-                sample=f"every {max(step, 1)}th row of the {W}x{H} frame, {reps} time(s) ({rays} rays per pass, {dt:.2f} s in all; "
-                       f"{st['debug']} extra debug queries per pass executed but not counted)")
+        probe = s.render(cam, f, W, H, start_depth=start_depth, want_ids=False, threads=threads, row_step=64)
+        tp = time.perf_counter() - t0
+        step = 1
+        while tp * 64 / step > budget and step < 64:
+            step *= 2
+        # a sample of about `budget` seconds: every step-th row of the frame, repeated while time remains
+        reps, dt, r = 0, 0.0, probe
+        while reps == 0 or (dt + dt / reps <= budget and reps < 64):
+            t0 = time.perf_counter()
+            r = s.render(cam, f, W, H, start_depth=start_depth, want_ids=False, threads=threads, row_step=step)
+            dt += time.perf_counter() - t0
+            reps += 1
+        st = r["stats"]
+        rays = st["primary"] + st["shadow"] + st["secondary"]
+        return rays * reps / dt / 1e6, (f"every {max(step, 1)}th row of the {W}x{H} frame, {reps} time(s) ({rays} rays per pass, {dt:.2f} s in all; "
+                                        f"{st['debug']} extra debug queries per pass executed but not counted)")
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    v_all, sample = timed(threads, 0.75 * budget_s)
+    v_one, sample_one = timed(1, 0.25 * budget_s)
+    return dict(value=v_all, unit="Mrays/s", cores=threads, kind="port", sample=sample, cpu_model=cpu_model(),
+                host_cpus=os.cpu_count(), value_1_thread=v_one, sample_1_thread=sample_one)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="dragon_glossy_bloom", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0, help="default: the workload's (1920 unless it says otherwise)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--obj", default=None, help="Wavefront OBJ to use where a workload names the dragon")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cull", action="store_true", help="traverse exactly as the reference (no distance culling)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="frames queued at once, each on its own stream (1..4)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -108,11 +134,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    api.check(api.lib().rt_set_device(local_rank))
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank % n_dev  # ranks may share a GPU (rehearsals on a one-GPU box)
+    torch.cuda.set_device(device_index)
+    api.check(api.lib().rt_set_device(device_index))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", device_index)
 
     wl = WORKLOADS[args.workload]
     W, H = args.width or wl.get("width", 1920), args.height or wl.get("height", 1080)
@@ -129,75 +160,107 @@ def main():
         if wl.get("orbit") else None
     region = api.Region(8, rank, world)
     flags = api.RT_RENDER_NO_CULL if args.no_cull else 0
-    stream = torch.cuda.current_stream().cuda_stream
 
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    scratch = torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev)
+    F = max(1, min(4, args.frames_in_flight))
+    flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    frames = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    scratch = [torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev) for _ in range(F)]
+    host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(F)]  # what the caller's Screen::pixels() aliases
     from raytracer_amd.stripes import StripePlan
-    plan = StripePlan(H, W, rank, world, stripe_rows=8, device=dev)
+    plans = [StripePlan(H, W, rank, world, stripe_rows=8, device=dev if args.backend == "nccl" else "cpu") for _ in range(F)]
 
-    ev_r0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_r1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev_r0[i].record()
-        scene.render_device(cams[i] if (cams and i is not None) else cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region,
-                            flags=flags, stream=stream)
-        if i is not None:
-            ev_r1[i].record()
-        plan.gather(frame, dist)
-        if feat.enableBloomEffect:
-            api.bloom_device(frame.data_ptr(), scratch.data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
-                             feat.bloomFilterIntensity, stream=stream)
+    def step(i, c=None, ev=None, fl=None):
+        """Frame i: queued on stream i % F; nothing waits on the host."""
+        k = i % F
+        st = streams[k]
+        with torch.cuda.stream(st):
+            if ev:
+                ev[0].record(st)
+            scene.render_device(c or cam, feat, W, H, wl["start_depth"], frames[k].data_ptr(), region=region,
+                                flags=flags_timed if fl is None else fl, stream=st.cuda_stream)
+            if ev:
+                ev[1].record(st)
+            if world > 1:
+                if args.backend == "nccl":
+                    plans[k].gather(frames[k], dist)
+                else:  # stripes through host memory: this rank's stripes down, everyone's up
+                    st.synchronize()
+                    cpu = frames[k].cpu()
+                    plans[k].gather(cpu, dist)
+                    frames[k].copy_(cpu)
+            if feat.enableBloomEffect:
+                api.bloom_device(frames[k].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
+                                 feat.bloomFilterIntensity, stream=st.cuda_stream)
+            host[k].copy_(frames[k], non_blocking=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i, cams[i % len(cams)] if cams else None)
     barrier()
-    stats = scene.sync(stream)  # ray counters of this rank's share of one frame
+    stats = scene.sync(streams[(args.warmup - 1) % F].cuda_stream if args.warmup else streams[0].cuda_stream)  # this rank's share of one frame
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, cams[i] if cams else None)
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # one frame with nothing else queued: its latency, and the duration of the rt_render launch sequence by itself
+    # (events on the stream the launches run on)
+    alone, kernel_ms = [], []
+    for i in range(6):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i, cams[i % len(cams)] if cams else None, ev, flags)
+        torch.cuda.synchronize()
+        alone.append((time.perf_counter() - t1) * 1e3)
+        kernel_ms.append(ev[0].elapsed_time(ev[1]))
+    alone_ms, kernel_ms = float(np.median(alone[1:])), float(np.median(kernel_ms[1:]))
+
+    s0 = streams[0].cuda_stream
     if cams:  # every frame of the sweep has its own ray count: recount them outside the timed region
         tot = [0, 0, 0, 0]
         for c in cams:
-            scene.render_device(c, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region, flags=flags, stream=stream)
-            st = scene.sync(stream)
+            scene.render_device(c, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region, flags=flags, stream=s0)
+            st = scene.sync(s0)
             for k, v in enumerate((st.primaryRays, st.shadowRays, st.secondaryRays, st.pixels)):
                 tot[k] += v / len(cams)
-        rays_rank = torch.tensor(tot, dtype=torch.float64, device=dev)
+        rays_rank = torch.tensor(tot, dtype=torch.float64)
     else:
-        rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64)
+    tmax = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
+        if args.backend == "nccl":
+            rays_rank, tmax = rays_rank.to(dev), tmax.to(dev)
         dist.all_reduce(rays_rank)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     rays_frame = float(rays_rank[:3].sum().item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_r0, ev_r1)]))
 
-    # Algorithmic bytes of rank 0's render launch (one rt_render = a fixed sequence of kernels on one stream,
-    # dominated by the trace kernels): per ray 64 B per node-pair step + 36 B per triangle test of the
-    # REFERENCE traversal (no culling) + 28 B ray in + 16 B hit out, plus 12 B per pixel written.  The
-    # duration is measured with events on the stream the launch runs on.
-    scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), region=region,
-                        flags=api.RT_RENDER_NO_CULL | api.RT_RENDER_COUNT_WORK, stream=stream)
-    work = scene.sync(stream)
-    alg_bytes = 64.0 * work.nodePairSteps + 36.0 * work.triangleTests + 44.0 * work.rays + 12.0 * work.pixels
+    # Algorithmic bytes of rank 0's render launch (one rt_render = a fixed sequence of kernels on one stream, dominated by
+    # the trace kernels): per ray 64 B per node-pair step + 36 B per triangle test + 28 B ray in + 16 B hit out, plus 12 B
+    # per pixel written.  Steps and tests are counted by a counting pass of the walk the frame is timed with (distance
+    # culling on, the caller's tree); the same figure for the reference's own walk, which visits every box a ray enters
+    # (no culling), is reported beside it and is not the basis of `achieved`.
+    def counted(fl):
+        scene.render_device(cam, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region, flags=fl | api.RT_RENDER_COUNT_WORK, stream=s0)
+        wk = scene.sync(s0)
+        return wk, 64.0 * wk.nodePairSteps + 36.0 * wk.triangleTests + 44.0 * wk.rays + 12.0 * wk.pixels
+    work, alg_bytes = counted(flags)
+    ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:
         try:
-            traffic = json.load(open(tpath)).get(args.workload if world == 1 else "", None)
+            tj = json.load(open(tpath))
+            traffic = tj.get(args.workload)
+            traffic_note = tj.get("_measured")
         except Exception:
             traffic = None
 
@@ -216,16 +279,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "ms_per_frame_alone": alone_ms,
+            "mrays_per_s_one_frame_alone": rays_frame / world / alone_ms / 1e3 if world == 1 else None,
             "config": {"workload": args.workload, "description": wl["desc"], "width": W, "height": H,
                        "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
-                       "rays_per_frame": int(rays_frame),
-                       "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (", RCCL all-gather" if world > 1 else ""),
+                       "rays_per_frame": int(rays_frame), "frames_in_flight": F,
+                       "step": "rt_render" + (" + stripe all-gather" if world > 1 else "") + " + rt_bloom + frame copy to pinned host memory",
+                       "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-gather" if world > 1 else ""),
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "rt_render launch (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": "rt_render launch sequence of one frame alone (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "node_pairs_per_ray": work.nodePairSteps / max(work.rays, 1), "tri_tests_per_ray": work.triangleTests / max(work.rays, 1)},
+                         "node_pairs_per_ray": work.nodePairSteps / max(work.rays, 1), "tri_tests_per_ray": work.triangleTests / max(work.rays, 1),
+                         "reference_walk": {"bytes_per_launch": ref_bytes, "gbs_over_kernel_ms": ref_bytes / (kernel_ms * 1e-3) / 1e9,
+                                            "node_pairs_per_ray": ref_work.nodePairSteps / max(ref_work.rays, 1),
+                                            "tri_tests_per_ray": ref_work.triangleTests / max(ref_work.rays, 1)}},
         }
     if world > 1:
         dist.barrier()

@@ -81,6 +81,12 @@ enum {
                                   for traversal cost alone, and accept what they find only when it is provably what
                                   the reference's walk (src/bvh.cpp:235-370) reports; the rest is traced again in
                                   the reference's tree.  Results are identical either way. */
+    RT_RENDER_OVERLAPPED = 16, /* flag: the caller keeps several frames queued on different streams (frames are independent:
+                                  main.cpp renders one per camera, src/main.cpp:515-526).  A scene holds one set of frame
+                                  buffers per stream (up to four), so such frames overlap on the GPU; with this flag
+                                  the launches of a frame are sized for the throughput of the overlapped frames rather
+                                  than for the latency of a frame that has the GPU to itself.  Frames are identical
+                                  either way. */
     RT_RENDER_SERIAL = 4       /* flag: evaluate each pixel as one depth-first recursion and sum radiance in the
                                   reference's nested float order (src/recursive.cpp:25-83); the default pipeline
                                   defers shadow rays and last-level rays and sums per pixel in fixed point.
@@ -182,7 +188,11 @@ int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t fil
 int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, float threshold, float intensity,
                     void* stream);
 
-/* Wait for the work queued on `stream` by the calls above and fetch the scene's ray counters.  It also notes how many
+/* Wait for the work queued on `stream` by the calls above and fetch the ray counters of the last frame queued on that
+ * stream (a scene keeps the buffers and counters of a frame per stream: see RT_RENDER_OVERLAPPED; a stream must not be
+ * destroyed while the scene lives).  RT_ERR_LIMIT reports a frame that is incomplete: a queue of the default pipeline
+ * overflowed, or a single contribution to a pixel reached 4e6 in magnitude, beyond the fixed-point pixel sums of the
+ * default pipeline (RT_RENDER_SERIAL has neither limit; rt_render_image falls back to it by itself).  It also notes how many
  * rays each round of the frame held: the next rt_render of the same size, depth, flags, features and region leaves out
  * the launches that only serve larger rounds (a hint - the frame is the same whatever the plan says). */
 int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);

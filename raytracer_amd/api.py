@@ -15,7 +15,7 @@ f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT = range(6)
-RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_TREE = 1, 2, 4, 8
+RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_TREE, RT_RENDER_OVERLAPPED = 1, 2, 4, 8, 16
 RT_BLOOM_STATIC_MAX_PIXELS = 1 << 21
 NO_HIT = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)

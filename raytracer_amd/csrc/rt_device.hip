@@ -98,6 +98,8 @@ struct rt_scene {
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
+    uint32_t laneModeAboveOverlapped = 65536, queryStepBudgetOverlapped = 20; // the same two for frames that overlap with others
+                                     // (RT_RENDER_OVERLAPPED; RT_AMD_T1_OVERLAPPED, RT_AMD_QBUDGET_OVERLAPPED)
     bool quadTrace = false;          // group launches in a query tree run four lanes per ray (RT_AMD_QUAD_TRACE; default: 8 or 16)
     int pathQuads = 0;               // pixel-per-lane mode with a query tree: 1 = four lanes per pixel (frames in LDS), 2 = the same with frames in
                                      // global memory, 0 = one lane per pixel (RT_AMD_PATH_QUADS)
@@ -1771,6 +1773,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_T1_OVERLAPPED")) s->laneModeAboveOverlapped = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
         const int g = atoi(e);
         if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) s->groupLanes = (uint32_t)g;
@@ -1878,6 +1882,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     w.lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
     const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
+    // a frame that shares the GPU with others: one ray per lane (cheaper per ray, slower for the stage's longest ray) from fewer rays on
+    const bool overlapped = (flags & RT_RENDER_OVERLAPPED) != 0;
+    const uint32_t laneModeAbove = overlapped ? scene->laneModeAboveOverlapped : scene->laneModeAbove;
+    const uint32_t queryStepBudget = overlapped ? scene->queryStepBudgetOverlapped : scene->queryStepBudget;
     const uint32_t fullGrid = (nWork + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
     if (grid > fullGrid) grid = fullGrid;
@@ -2104,7 +2112,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // every ray of a group launch (at most laneModeAbove of them) gets its group from the grid position
     const uint32_t groupRaysPerBlock = kBlock / (scene->groupLanes > 1 ? scene->groupLanes : 8u);
     const uint32_t groupGrid = scene->groupBlocksPerCU ? (uint32_t)scene->numCUs * scene->groupBlocksPerCU
-                                                       : (scene->laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
+                                                       : (laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     uint32_t gridNow = groupGrid; // workgroups of the next group launch: fewer where few rays are expected (the rest is fetched in chunks)
     auto launch_one = [&](uint32_t groupLanes, bool query) {
@@ -2163,11 +2171,11 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         if (useQuery) w.fallSlots.push_back(nextFetch);
         uint32_t* fallCount = w.d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
-        T.runLo = scene->laneModeAbove;
-        const uint32_t budget = (count || smallRound) ? 0u : (useQuery ? scene->queryStepBudget : scene->stepBudget);
+        T.runLo = laneModeAbove;
+        const uint32_t budget = (count || smallRound) ? 0u : (useQuery ? queryStepBudget : scene->stepBudget);
         T.stepBudget = budget, T.longCount = longCount;
         if (!smallRound) launch_one(1, useQuery); // the plan says few rays: the group launch takes them, however many there are
-        T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : scene->laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
+        T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
         // a round of few rays is bound by its longest ray: 16 lanes per ray shorten that chain (more rays: fewer rays per wave cost more)
         const bool wide = smallRound && useQuery && scene->groupLanes == 8 && expected < scene->wideBelow;
         const uint32_t rpb = wide ? groupRaysPerBlock / 2 : groupRaysPerBlock;
@@ -2299,7 +2307,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         // the camera kernel emits exactly one ray per active state and counts them once
         // a round counts as small when the plan's frame would have sent it to the group kernel (which is about as fast as the
         // other schedule up to half as many rays again, should this frame's round be larger)
-        const bool smallRound = planned && w.roundRays[r - 1] < scene->laneModeAbove;
+        const bool smallRound = planned && w.roundRays[r - 1] < laneModeAbove;
         launch_trace(w.d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? w.d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
                      smallRound ? w.roundRays[r - 1] : 0u);
         P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);

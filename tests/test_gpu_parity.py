@@ -295,6 +295,23 @@ def test_striped_regions_tile_the_frame():
     assert np.array_equal(got.view(np.uint32), full["rgb"].view(np.uint32))
 
 
+def test_glossy_16_samples_renders_by_default():
+    """numGlossySamples = 16 from rayDepth 2: a pixel's chain of dependent rays (up to 1 + 16 + 256 + 4096) is beyond what
+    the round-based path stage accepts; the default pipeline renders it all the same (a persistent launch with one pixel
+    per lane), equal to the oracle and to the depth-first kernel."""
+    g, o, _ = scene_pair("knot")
+    fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=16)
+    W, H = 64, 36
+    cg, co = both_cameras(W, H, dist=2.0)
+    rg = g.render_image(cg, fg, W, H, start_depth=2)
+    rs = g.render_image(cg, fg, W, H, start_depth=2, flags=api.RT_RENDER_SERIAL)
+    ro = o.render(co, fo, W, H, start_depth=2)
+    compare_frames(rg, ro, "knot glossy x16")
+    assert abs(rg["stats"].rays - (ro["stats"]["primary"] + ro["stats"]["shadow"] + ro["stats"]["secondary"])) <= 1e-4 * rg["stats"].rays
+    assert rg["stats"].rays > 200 * W * H  # deep trees were walked
+    assert np.abs(rg["rgb"] - rs["rgb"]).max() < 1e-5
+
+
 def test_frames_on_several_streams_overlap_without_mixing():
     """Frames of one scene queued on different streams run on buffers of their own: five cameras on five streams at once
     (more streams than the scene keeps buffer sets, so one set is taken over) give the frames and ray counts of the same
