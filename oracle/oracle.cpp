@@ -646,19 +646,19 @@ V3 contributionPointLight(State& st, V3 lpos, V3 lcol, const Ray& ray, const Hit
     V3 v = -ray.direction;
     return computeShading(st, v, l, visibleLight, h);
 }
-V3 computeLightContribution(State& st, const Ray& ray, const HitInfo& h) // :262-276
+V3 computeLightContribution(State& st, const Ray& ray, const HitInfo& h, ShadowQuery query = sceneShadowQuery, void* user = nullptr) // :262-276
 {
     V3 Lo = v3(0.0f);
     const uint32_t numSamples = st.features.numShadowSamples;
     for (const Light& L : st.scene.lights) {
         if (L.type == 0) {
-            Lo += contributionPointLight(st, v3(L.f), v3(L.f + 3), ray, h, sceneShadowQuery, nullptr);
+            Lo += contributionPointLight(st, v3(L.f), v3(L.f + 3), ray, h, query, user);
         } else if (L.type == 1) { // :178-195 - note the sampled POSITION is passed as the light direction
             V3 contribution = v3(0.0f);
             for (uint32_t i = 0; i < numSamples; i++) {
                 V3 position, color;
                 sampleSegmentLight(st.sampler.next_1d(), L.f, position, color);
-                V3 lightColor = visibilityOfLightSample(st, position, color, ray, sceneShadowQuery, nullptr);
+                V3 lightColor = visibilityOfLightSample(st, position, color, ray, query, user);
                 contribution += computeShading(st, -ray.direction, position, lightColor, h) / (1.0f * numSamples);
             }
             Lo += contribution;
@@ -670,7 +670,7 @@ V3 computeLightContribution(State& st, const Ray& ray, const HitInfo& h) // :262
                 smp.x = st.sampler.next_1d();
                 smp.y = st.sampler.next_1d();
                 sampleParallelogramLight(smp, L.f, position, color);
-                V3 lightColor = visibilityOfLightSample(st, position, color, ray, sceneShadowQuery, nullptr);
+                V3 lightColor = visibilityOfLightSample(st, position, color, ray, query, user);
                 contribution += computeShading(st, -ray.direction, position, lightColor, h) / (1.0f * numSamples);
             }
             Lo += contribution;
@@ -1161,6 +1161,82 @@ void orc_point_light(int enableShadows, int hit, float tHit, const float* lightP
     put(shadowRay6, sc.calls ? sc.last.origin : v3(0.0f));
     put(shadowRay6 + 3, sc.calls ? sc.last.direction : v3(0.0f));
     *nQueries = sc.calls;
+}
+namespace {
+// A scripted SEQUENCE of answers (7 floats each: hit, relative, value, kd3, transparency): the reported distance is
+// `value`, or - with `relative` - the distance from the ray's origin to `target` plus `value`; past the script's end
+// every query misses.  Every ray asked for is kept.
+struct ScriptSeq {
+    const float* script;
+    int n;
+    V3 target;
+    std::vector<Ray> rays;
+};
+bool sequenceQuery(void* user, State&, Ray& ray, HitInfo& hit)
+{
+    ScriptSeq* s = static_cast<ScriptSeq*>(user);
+    const int k = (int)s->rays.size();
+    s->rays.push_back(ray);
+    if (k >= s->n) return false;
+    const float* a = s->script + 7 * k;
+    if (a[0] == 0.0f) return false;
+    ray.t = (a[1] != 0.0f) ? length(s->target - ray.origin) + a[2] : a[2];
+    hit.material.kd = v3(a + 3);
+    hit.material.transparency = a[6];
+    return true;
+}
+void putRays(const ScriptSeq& sc, int maxRays, float* rays6, int* nQueries)
+{
+    *nQueries = (int)sc.rays.size();
+    for (int k = 0; k < maxRays; k++) {
+        put(rays6 + 6 * k, k < (int)sc.rays.size() ? sc.rays[k].origin : v3(0.0f));
+        put(rays6 + 6 * k + 3, k < (int)sc.rays.size() ? sc.rays[k].direction : v3(0.0f));
+    }
+}
+}
+// computeLightContribution (src/light.cpp:262-276) over `nLights` lights (22 floats each: type, then the struct's floats)
+// with every visibility query answered by the script.  out3: the contribution; nextDraw: the sampler's next draw after
+// the call; rays6: the first maxRays rays asked for (origin, direction).
+void orc_light_contribution(int enableShading, int enableShadows, int enableTransparency, int model, uint32_t numShadowSamples,
+                            const float* lights22, int nLights, uint32_t seed, const float* ray7, const float* normal3, const float* kd3,
+                            const float* ks3, float shininess, float transparency, const float* script7, int nScript, float* out3,
+                            float* nextDraw, float* rays6, int maxRays, int* nQueries)
+{
+    orc_scene scene;
+    for (int l = 0; l < nLights; l++) {
+        Light L;
+        L.type = (int)lights22[22 * l];
+        memcpy(L.f, lights22 + 22 * l + 1, sizeof(L.f));
+        scene.lights.push_back(L);
+    }
+    orc_features f = defaultFeatures();
+    f.enableShading = enableShading, f.enableShadows = enableShadows, f.enableTransparency = enableTransparency;
+    f.shadingModel = model, f.numShadowSamples = numShadowSamples;
+    State st { scene, f, { seed }, nullptr };
+    Ray r;
+    r.origin = v3(ray7), r.direction = v3(ray7 + 3), r.t = ray7[6];
+    HitInfo h;
+    h.normal = v3(normal3);
+    h.material.kd = v3(kd3), h.material.ks = v3(ks3);
+    h.material.shininess = shininess, h.material.transparency = transparency;
+    ScriptSeq sc { script7, nScript, r.origin + r.t * r.direction, {} };
+    put(out3, computeLightContribution(st, r, h, sequenceQuery, &sc));
+    *nextDraw = st.sampler.next_1d();
+    putRays(sc, maxRays, rays6, nQueries);
+}
+// visibilityOfLightSampleTransparency (src/light.cpp:107-136) with the occluders scripted
+void orc_visibility_transparency(const float* lightPos3, const float* lightCol3, const float* ray7, const float* script7, int nScript,
+                                 float* out3, float* rays6, int maxRays, int* nQueries)
+{
+    orc_scene scene;
+    orc_features f = defaultFeatures();
+    f.enableShadows = 1, f.enableTransparency = 1;
+    State st { scene, f, { 7u }, nullptr };
+    Ray r;
+    r.origin = v3(ray7), r.direction = v3(ray7 + 3), r.t = ray7[6];
+    ScriptSeq sc { script7, nScript, r.origin + r.t * r.direction, {} };
+    put(out3, visibilityTransparency(st, v3(lightPos3), v3(lightCol3), r, sequenceQuery, &sc));
+    putRays(sc, maxRays, rays6, nQueries);
 }
 void orc_reflect(const float* ray7, const float* normal3, float* outRay7)
 {

@@ -103,6 +103,14 @@ void orc_sample_parallelogram(const float* light21, const float* sample2, float*
 void orc_point_light(int enableShadows, int hit, float tHit, const float* lightPos3, const float* lightCol3,
                      const float* ray7, const float* normal3, const float* kd3, const float* ks3, float shininess,
                      float* out3, float* shadowRay6, int* nQueries);
+/* computeLightContribution (src/light.cpp:262-276) / visibilityOfLightSampleTransparency (:107-136) with every visibility
+ * query answered from a script (7 floats per answer: hit, relative, value, kd3, transparency). */
+void orc_light_contribution(int enableShading, int enableShadows, int enableTransparency, int model, uint32_t numShadowSamples,
+                            const float* lights22, int nLights, uint32_t seed, const float* ray7, const float* normal3, const float* kd3,
+                            const float* ks3, float shininess, float transparency, const float* script7, int nScript, float* out3,
+                            float* nextDraw, float* rays6, int maxRays, int* nQueries);
+void orc_visibility_transparency(const float* lightPos3, const float* lightCol3, const float* ray7, const float* script7, int nScript,
+                                 float* out3, float* rays6, int maxRays, int* nQueries);
 void orc_reflect(const float* ray7, const float* normal3, float* outRay7);
 void orc_passthrough(const float* ray7, float* outRay7);
 void orc_basis(const float* r3, float* out9);

@@ -114,6 +114,36 @@ struct ScriptedBVH : public BVHInterface {
     uint32_t numLeaves() const override { return 0; }
 };
 
+// The same with a scripted SEQUENCE of answers, for code that queries the BVH several times per call (area lights,
+// light through transparent occluders).  Answer k: {hit, relative, value, kd3, transparency}; the reported distance is
+// `value`, or - with `relative` - the distance from the ray's origin to `target` plus `value`.  Past the script's end
+// every query misses.  Every ray asked for is kept.
+struct SequenceBVH : public BVHInterface {
+    std::vector<float> script; // 7 floats per answer
+    glm::vec3 target { 0 };
+    mutable std::vector<Ray> rays;
+    std::vector<Node> m_nodes;
+    std::vector<Primitive> m_prims;
+    bool intersect(RenderState&, Ray& ray, HitInfo& hitInfo) const override
+    {
+        const size_t k = rays.size();
+        rays.push_back(ray);
+        if (7 * k + 6 >= script.size()) return false;
+        const float* a = &script[7 * k];
+        if (a[0] == 0.0f) return false;
+        ray.t = (a[1] != 0.0f) ? glm::length(target - ray.origin) + a[2] : a[2];
+        hitInfo.material.kd = glm::vec3(a[3], a[4], a[5]);
+        hitInfo.material.transparency = a[6];
+        return true;
+    }
+    std::span<const Node> nodes() const override { return m_nodes; }
+    std::span<Node> nodes() override { return m_nodes; }
+    std::span<const Primitive> primitives() const override { return m_prims; }
+    std::span<Primitive> primitives() override { return m_prims; }
+    uint32_t numLevels() const override { return 0; }
+    uint32_t numLeaves() const override { return 0; }
+};
+
 // ---- scene dumps: output of the reference's own loader (scene.cpp + mesh.cpp) ---
 static void dumpScene(const char* name, SceneType type)
 {
@@ -324,6 +354,151 @@ int main(int argc, char** argv)
         }
         writeF32("pointlight_in", in, { N, 26 });
         writeF32("pointlight_out", out, { N, 10 });
+    }
+
+    // ---------------- light.cpp: computeLightContribution over point / segment / parallelogram lights ----------------
+    // (src/light.cpp:151-232, 247-276) with scripted visibility: sampler draw order, the per-sample division, the sampled
+    // POSITION handed to computeShading as the light direction, binary and transparent visibility of every sample.
+    {
+        Rng rng(12);
+        const size_t N = 384, kMaxLights = 3, kScript = 24, kMaxRays = 24;
+        std::vector<float> in, out;
+        std::vector<uint32_t> seeds;
+        for (size_t i = 0; i < N; i++) {
+            Scene sc2 = scene;
+            sc2.lights.clear();
+            const size_t nLights = 1 + rng.u32() % kMaxLights;
+            std::vector<float> lrec(22 * kMaxLights, 0.0f);
+            for (size_t l = 0; l < kMaxLights; l++) lrec[22 * l] = -1.0f; // unused slot
+            for (size_t l = 0; l < nLights; l++) {
+                const uint32_t ty = (i < 32) ? (uint32_t)(i % 3) : rng.u32() % 3;
+                float* r = &lrec[22 * l];
+                r[0] = (float)ty;
+                if (ty == 0) {
+                    PointLight pl { rng.v3(-2, 2), rng.v3(0, 1) };
+                    memcpy(r + 1, &pl, sizeof(pl));
+                    sc2.lights.push_back(pl);
+                } else if (ty == 1) {
+                    SegmentLight sl { rng.v3(-2, 2), rng.v3(-2, 2), rng.v3(0, 1), rng.v3(0, 1) };
+                    memcpy(r + 1, &sl, sizeof(sl));
+                    sc2.lights.push_back(sl);
+                } else {
+                    ParallelogramLight pg { rng.v3(-1, 1), rng.v3(-1, 1), rng.v3(-1, 1), rng.v3(0, 1), rng.v3(0, 1), rng.v3(0, 1), rng.v3(0, 1) };
+                    memcpy(r + 1, &pg, sizeof(pg));
+                    sc2.lights.push_back(pg);
+                }
+            }
+            Features f {};
+            f.enableShading = (i % 9) != 8;
+            f.enableShadows = (i % 5) != 4;
+            f.enableTransparency = (i % 4) == 3;
+            f.shadingModel = (i % 3) ? ShadingModel::Phong : ShadingModel::Lambertian;
+            f.numShadowSamples = 1 + rng.u32() % 5;
+            SequenceBVH qbvh;
+            const uint32_t seed = rng.u32();
+            RenderState state { .scene = sc2, .features = f, .bvh = qbvh, .sampler = { seed } };
+            Ray ray;
+            ray.origin = rng.v3(-3, 3);
+            ray.direction = glm::normalize(rng.v3(-1, 1));
+            ray.t = rng.uni(0.5f, 4.0f);
+            HitInfo hi;
+            hi.normal = rng.v3(-1, 1);
+            hi.barycentricCoord = glm::vec3(0);
+            hi.texCoord = glm::vec2(0);
+            hi.material.kd = rng.v3(0, 1);
+            hi.material.ks = rng.v3(0, 1);
+            hi.material.shininess = rng.uni(1.0f, 50.0f);
+            hi.material.transparency = (i % 2) ? 1.0f : rng.uni(0.1f, 0.9f);
+            qbvh.target = ray.origin + ray.t * ray.direction;
+            // answers: mostly "the shaded surface itself" (relative, within / just outside the windows of 5e-4 and 1e-5),
+            // some occluders nearer the light, some misses
+            const float deltas[] = { 0.0f, 4e-6f, -4e-6f, 4e-4f, -4e-4f, 6e-4f, 2e-5f, -0.3f };
+            for (size_t k = 0; k < kScript; k++) {
+                const uint32_t kind = rng.u32() % 8;
+                float a[7] = { kind == 7 ? 0.0f : 1.0f, 1.0f, deltas[rng.u32() % 8], 0, 0, 0, 0 };
+                if (kind >= 5 && kind < 7) a[1] = 0.0f, a[2] = rng.uni(0.05f, 0.6f); // an occluder close to the light
+                glm::vec3 kd = rng.v3(0, 1);
+                a[3] = kd.x, a[4] = kd.y, a[5] = kd.z, a[6] = (kind % 2) ? 1.0f : rng.uni(0.1f, 0.9f);
+                // with transparency the walk of one sample only ends on a surface within 1e-5 of the shaded point or on a
+                // miss: make every fourth answer such an end
+                if (f.enableTransparency && k % 4 == 3) a[0] = (k % 8 == 3) ? 0.0f : 1.0f, a[1] = 1.0f, a[2] = 0.0f;
+                qbvh.script.insert(qbvh.script.end(), a, a + 7);
+            }
+            glm::vec3 Lo = computeLightContribution(state, ray, hi);
+            const float next = state.sampler.next_1d(); // pins the sampler's state after the call
+            in.insert(in.end(), { f.enableShading ? 1.f : 0.f, f.enableShadows ? 1.f : 0.f, f.enableTransparency ? 1.f : 0.f,
+                                  (float)(int)f.shadingModel, (float)f.numShadowSamples, (float)nLights });
+            in.insert(in.end(), lrec.begin(), lrec.end());
+            push3(in, ray.origin); push3(in, ray.direction); in.push_back(ray.t);
+            push3(in, hi.normal); push3(in, hi.material.kd); push3(in, hi.material.ks); in.push_back(hi.material.shininess);
+            in.push_back(hi.material.transparency);
+            in.insert(in.end(), qbvh.script.begin(), qbvh.script.end());
+            seeds.push_back(seed);
+            push3(out, Lo);
+            out.push_back(next);
+            out.push_back((float)qbvh.rays.size());
+            for (size_t k = 0; k < kMaxRays; k++) {
+                if (k < qbvh.rays.size()) { push3(out, qbvh.rays[k].origin); push3(out, qbvh.rays[k].direction); }
+                else { push3(out, glm::vec3(0)); push3(out, glm::vec3(0)); }
+            }
+        }
+        writeF32("lightcontrib_in", in, { N, 6 + 22 * kMaxLights + 7 + 11 + 7 * kScript });
+        writeU32("lightcontrib_seed", seeds, { N });
+        writeF32("lightcontrib_out", out, { N, 5 + 6 * kMaxRays });
+    }
+    // ---------------- light.cpp: visibilityOfLightSampleTransparency (src/light.cpp:107-136) ----------------
+    // 0 to 4 occluders between the light and the shaded point, then the shaded surface itself (within or outside the
+    // 1e-5 window) or nothing.
+    {
+        Rng rng(13);
+        const size_t N = 256, kScript = 8, kMaxRays = 8;
+        std::vector<float> in, out;
+        for (size_t i = 0; i < N; i++) {
+            Features f {};
+            f.enableShadows = true, f.enableTransparency = true;
+            SequenceBVH qbvh;
+            RenderState state { .scene = scene, .features = f, .bvh = qbvh, .sampler = { 7u } };
+            Ray ray;
+            ray.origin = rng.v3(-3, 3);
+            ray.direction = glm::normalize(rng.v3(-1, 1));
+            ray.t = rng.uni(0.5f, 4.0f);
+            HitInfo hi;
+            hi.normal = rng.v3(-1, 1);
+            hi.barycentricCoord = glm::vec3(0);
+            hi.texCoord = glm::vec2(0);
+            glm::vec3 lpos = rng.v3(-2, 2), lcol = rng.v3(0, 1.5f);
+            qbvh.target = ray.origin + ray.t * ray.direction;
+            const size_t occluders = i % 5;
+            const float dist = glm::length(qbvh.target - lpos);
+            for (size_t k = 0; k < kScript; k++) {
+                glm::vec3 kd = rng.v3(0, 1);
+                float a[7] = { 1.0f, 0.0f, 0.0f, kd.x, kd.y, kd.z, rng.uni(0.0f, 1.0f) };
+                if (k < occluders) {
+                    a[2] = dist * rng.uni(0.05f, 0.3f); // measured from the ray's own origin, which moves on with every surface
+                } else if (k == occluders) {
+                    const uint32_t end = (uint32_t)(i / 5) % 4;
+                    a[1] = 1.0f;
+                    if (end == 0) a[2] = 0.0f;            // the shaded surface, exactly
+                    else if (end == 1) a[2] = 8e-6f;      // ... within the window
+                    else if (end == 2) a[0] = 0.0f;       // nothing: the walk ends on a miss
+                    else a[2] = 3e-5f;                    // just outside the window: the walk goes on (and then misses)
+                } else {
+                    a[0] = 0.0f;
+                }
+                qbvh.script.insert(qbvh.script.end(), a, a + 7);
+            }
+            glm::vec3 r = visibilityOfLightSampleTransparency(state, lpos, lcol, ray, hi);
+            push3(in, lpos); push3(in, lcol); push3(in, ray.origin); push3(in, ray.direction); in.push_back(ray.t);
+            in.insert(in.end(), qbvh.script.begin(), qbvh.script.end());
+            push3(out, r);
+            out.push_back((float)qbvh.rays.size());
+            for (size_t k = 0; k < kMaxRays; k++) {
+                if (k < qbvh.rays.size()) { push3(out, qbvh.rays[k].origin); push3(out, qbvh.rays[k].direction); }
+                else { push3(out, glm::vec3(0)); push3(out, glm::vec3(0)); }
+            }
+        }
+        writeF32("transvis_in", in, { N, 13 + 7 * kScript });
+        writeF32("transvis_out", out, { N, 4 + 6 * kMaxRays });
     }
 
     // ---------------- recursive.cpp: generateReflectionRay / generatePassthroughRay ----------------

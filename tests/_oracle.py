@@ -81,6 +81,9 @@ def lib():
                                        f32p, C.c_float, f32p]
     L.orc_sample_segment.argtypes = [f32p, C.c_float, f32p, f32p]
     L.orc_sample_parallelogram.argtypes = [f32p, f32p, f32p, f32p]
+    L.orc_light_contribution.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p, f32p, f32p,
+                                         C.c_float, C.c_float, f32p, C.c_int, f32p, f32p, f32p, C.c_int, C.POINTER(C.c_int)]
+    L.orc_visibility_transparency.argtypes = [f32p, f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_int, C.POINTER(C.c_int)]
     L.orc_point_light.argtypes = [C.c_int, C.c_int, C.c_float, f32p, f32p, f32p, f32p, f32p, f32p, C.c_float, f32p, f32p,
                                   C.POINTER(C.c_int)]
     L.orc_reflect.argtypes = [f32p, f32p, f32p]

@@ -732,6 +732,52 @@ def test_transparency_pass_through_rays(name, W, H, glossy):
     assert np.abs(r0["rgb"] - rg["rgb"]).max() > 1e-3
 
 
+def quads_scene(quads, light_pos):
+    """Horizontal quads (centre, half size, material) as two triangles each, normals up; materials: kd3, ks3, shininess, transparency
+    (a ninth value, "has a texture", is appended as 0)."""
+    pos, mesh, mats = [], [], []
+    for m, (c, h, mat) in enumerate(quads):
+        x0, x1, z0, z1, y = c[0] - h, c[0] + h, c[2] - h, c[2] + h, c[1]
+        a, b, cc, d = (x0, y, z0), (x1, y, z0), (x1, y, z1), (x0, y, z1)
+        pos += [[a, cc, b], [a, d, cc]]
+        mesh += [m, m]
+        mats.append(tuple(mat) + (0.0,))
+    pos = np.asarray(pos, np.float32)
+    nrm = np.zeros_like(pos)
+    nrm[:, :, 1] = 1.0
+    prims = scenes.pack_prims(mesh, pos, nrm, np.zeros((len(pos), 3, 2), np.float32))
+    return dict(prims=prims, materials=np.asarray(mats, np.float32), lights=scenes.point_light(light_pos).reshape(1, 22),
+                spheres=np.zeros((0, 12), np.float32))
+
+
+def test_light_through_transparent_occluders_matches_oracle():
+    """Shadows with transparency on a scene where the reference's walk from the light ends (src/light.cpp:107-136): an
+    opaque floor under two tinted transparent panes, one above the other.  A floor point is lit through no pane, one or
+    both; the light that arrives is what the oracle's restatement of the walk (pinned against light.cpp) computes, and the
+    64-surface cap of the kernel is never reached."""
+    floor = ((0.0, -0.5, 0.0), 2.0, (0.8, 0.8, 0.7, 0.0, 0.0, 0.0, 10.0, 1.0))
+    pane1 = ((0.1, 0.0, 0.0), 0.6, (0.9, 0.3, 0.2, 0.0, 0.0, 0.0, 10.0, 0.5))
+    pane2 = ((-0.2, 0.4, 0.1), 0.35, (0.2, 0.5, 0.9, 0.0, 0.0, 0.0, 10.0, 0.7))
+    sc = quads_scene([floor, pane1, pane2], (0.1, 1.6, -0.2))
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    W, H = 240, 160
+    cg, co = both_cameras(W, H, rot_deg=(35.0, 20.0, 0.0))
+    fg, fo = both_features(enableTransparency=1, enableReflections=0)
+    rg = g.render_image(cg, fg, W, H, start_depth=3)
+    ro = o.render(co, fo, W, H, start_depth=3)
+    compare_frames(rg, ro, "light through two panes")
+    gs, os_ = rg["stats"], ro["stats"]
+    assert (gs.primaryRays, gs.shadowRays, gs.secondaryRays) == (os_["primary"], os_["shadow"], os_["secondary"])
+    assert gs.shadowRays > 1.5 * gs.primaryRays * 0.3  # walks of several segments
+    # the panes do tint the floor: binary shadows give another frame, and so does no shadow at all
+    f1, _ = both_features(enableTransparency=0, enableReflections=0)
+    f2, _ = both_features(enableTransparency=1, enableReflections=0, enableShadows=0)
+    for other in (f1, f2):
+        r = g.render_image(cg, other, W, H, start_depth=3)
+        assert np.abs(r["rgb"] - rg["rgb"]).max() > 0.05
+
+
 def test_transparent_shadows_terminate():
     """With shadows on, the light of a sample is followed through transparent surfaces; the kernel stops the
     reference's (possibly endless) walk after 64 surfaces, so the frame always completes and stays finite."""
