@@ -69,7 +69,15 @@ typedef struct rt_stats {
     uint64_t stackOverflows; /* must be 0 */
     uint64_t referenceTreeQueries; /* queries of the last wavefront frame that were traced again in the caller's tree
                                       because the query tree's result could not be proven equal (see RT_RENDER_REFERENCE_TREE) */
+    uint64_t pipeline; /* which schedule rendered the frame: RT_PIPELINE_* */
 } rt_stats;
+
+enum {
+    RT_PIPELINE_DEPTH_FIRST = 0, /* one kernel, a lane walks a pixel's whole recursion (RT_RENDER_SERIAL, or a recursion tree
+                                    too long for the staged schedules) */
+    RT_PIPELINE_ROUNDS = 1,      /* staged: the rays a pixel's sampler depends on in frame-wide rounds, the rest as queued tasks */
+    RT_PIPELINE_PERSISTENT = 2   /* staged, with those rays walked pixel by pixel inside one persistent launch */
+};
 
 enum {
     RT_MAX_RAY_DEPTH = 6,      /* recursion continues while rayDepth < 6 (src/recursive.cpp:62) */

@@ -611,13 +611,18 @@ bool visibilityBinary(State& st, V3 lightPosition, const Ray& ray, ShadowQuery q
     bool expectedRayT = std::fabs(lightRay.t - length(ip - lightPosition)) <= 5e-4f;
     return intersects && expectedRayT;
 }
+// The reference's loop has no bound and never ends where the shaded surface is met a little off the shaded point.  Tests
+// that render such scenes set a bound (orc_set_shadow_walk_cap; 0 = none, the reference's behaviour): the number of
+// surfaces after which the walk stops, as the library under test documents for itself.
+static int g_shadowWalkCap = 0;
 V3 visibilityTransparency(State& st, V3 lightPosition, V3 lightColor, const Ray& ray, ShadowQuery q, void* user) // :107-136
 {
     V3 incoming = lightColor, prevLight = lightColor;
     V3 ip = ray.origin + ray.t * ray.direction;
     bool intersects = true, finalRayT = false;
     V3 lightRayOrigin = lightPosition;
-    while (intersects && !finalRayT) {
+    int met = 0;
+    while (intersects && !finalRayT && (g_shadowWalkCap == 0 || met++ < g_shadowWalkCap)) {
         Ray lightRay;
         lightRay.origin = lightRayOrigin;
         lightRay.direction = normalize(ip - lightRayOrigin);
@@ -914,6 +919,7 @@ orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const floa
     return s;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
+void orc_set_shadow_walk_cap(int surfaces) { g_shadowWalkCap = surfaces; }
 int orc_scene_set_texture(orc_scene* s, uint32_t material, const float* rgb, int width, int height)
 {
     if (!s || material >= s->materials.size()) return 1;

@@ -59,6 +59,9 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const float* materials9, uint32_t nMaterials,
                             const float* lights22, uint32_t nLights, const float* spheres12, uint32_t nSpheres);
 void orc_scene_destroy(orc_scene* s);
+/* Test aid, not reference behaviour: stop the walk through transparent occluders (src/light.cpp:107-136) after this many
+   surfaces (0 = never, as the reference). */
+void orc_set_shadow_walk_cap(int surfaces);
 /* Material::kdTexture of mesh `material`: width*height RGB floats, rows as decoded (top row first) - the layout of
  * Image::pixels (framework/src/image.cpp:33-55).  Null rgb removes it.  Used when enableTextureMapping is set. */
 int orc_scene_set_texture(orc_scene* s, uint32_t material, const float* rgb, int width, int height);

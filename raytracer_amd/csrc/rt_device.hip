@@ -1890,8 +1890,28 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
     if (grid > fullGrid) grid = fullGrid;
 
-    // pass-through rays and the walk through transparent occluders exist in the depth-first kernel only
-    if ((flags & RT_RENDER_SERIAL) || features->enableTransparency) {
+    // With transparency a hit can continue twice (reflection, then the pass-through ray): the sequential rays of a full
+    // recursion tree, one per round.  Depth-6 children of a glossy loop are deferred when no light draws from the sampler.
+    uint64_t transparentChain = 0;
+    if (features->enableTransparency) {
+        bool area = false;
+        for (int ty : scene->lightTypes) area = area || ty != 0;
+        const bool glossy = features->enableReflections && features->enableGlossyReflection;
+        uint64_t t = 1; // a ray at the depth limit
+        for (int d = RT_MAX_RAY_DEPTH - 1; d >= startDepth; d--) {
+            uint64_t refl = 0;
+            if (features->enableReflections) refl = !glossy ? t : ((!area && d == RT_MAX_RAY_DEPTH - 1) ? 0 : features->numGlossySamples * t);
+            t = std::min<uint64_t>(1 + refl + t, 1u << 24);
+        }
+        uint64_t nRays = features->numPixelSamples > 1 ? features->numPixelSamples : 1;
+        if (features->numPixelSamples > 1 && features->enableJitteredSampling) {
+            const uint64_t ns = (uint64_t)roundf(sqrtf((float)features->numPixelSamples));
+            nRays = ns * ns;
+        }
+        transparentChain = t * nRays;
+    }
+    // the depth-first kernel: on request, and for transparent frames whose recursion tree is too long for rounds
+    if ((flags & RT_RENDER_SERIAL) || transparentChain > kMaxRounds - 1) {
         RenderParams P;
         P.S = scene->view;
         P.cam = *camera;
@@ -1941,7 +1961,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
     // The path stage - the rays whose outcome the pixel's sampler depends on - runs as one persistent launch in which a group
     // of lanes owns a pixel from its first ray to its last (path_kernel), or, without it, in frame-wide rounds.
-    const bool usePathGroup = scene->pathMode == 1 && groupOk && cull && !count && (scene->groupLanes == 8 || scene->groupLanes == 16);
+    const bool usePathGroup = scene->pathMode == 1 && groupOk && cull && !count && (scene->groupLanes == 8 || scene->groupLanes == 16)
+        && !features->enableTransparency; // the persistent schedules know no pass-through rays
     // Rounds a full recursion tree needs when its loops are walked one child per round (batched loops need fewer): beyond what
     // the round-based stage accepts, the pixel-per-lane launch takes the frame, whose chains may be as long as they like.
     bool longChains = false;
@@ -1956,7 +1977,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         links *= std::max<uint64_t>(features->numPixelSamples, ns * ns);
         longChains = links > kMaxRounds / 2;
     }
-    const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count;
+    const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count && !features->enableTransparency;
     const bool usePath = usePathGroup || usePathLane;
     // (rounds only) a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
     uint32_t batchRays = 0;
@@ -1965,7 +1986,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
         if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && N * (N + 1) / 2 <= kMaxBatchRays
-            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !getenv("RT_AMD_NO_BATCH")) // a counting pass walks only the reference's rays
+            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !features->enableTransparency
+            && !getenv("RT_AMD_NO_BATCH")) // a counting pass walks only the reference's rays
             batchRays = N * (N + 1) / 2;
     }
     const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
@@ -2053,6 +2075,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         }
         chain *= nRays;
     }
+    if (features->enableTransparency) chain = transparentChain;
     if (usePath) chain = 0; // no rounds: a pixel's chain may be as long as it likes
     if (chain > kMaxRounds - 1 || 6 * nChunks + 32 > kMaxTraceLaunches - 6 * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
@@ -2325,7 +2348,23 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         P.chunkTasks = (w.shadeCap - P.chunkBase < chunkTasks) ? w.shadeCap - P.chunkBase : chunkTasks;
         if (shadows) {
             hipLaunchKernelGGL(shadow_gen_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-            launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
+            if (features->enableTransparency) { // every sample is followed through the surfaces on its way, in the caller's tree
+                T.S = scene->view;
+                T.fetch = w.d_roundCounts + nextFetch++;
+#define RT_WALK_CASE(CULL, COUNT)                                                                                              \
+    do {                                                                                                                       \
+        if (stackClass == 0) hipLaunchKernelGGL((shadow_walk_kernel<CULL, COUNT, 16>), dim3(traceGrid), dim3(kBlock), 0, st, P, T);     \
+        else if (stackClass == 1) hipLaunchKernelGGL((shadow_walk_kernel<CULL, COUNT, 24>), dim3(traceGrid), dim3(kBlock), 0, st, P, T); \
+        else hipLaunchKernelGGL((shadow_walk_kernel<CULL, COUNT, 32>), dim3(traceGrid), dim3(kBlock), 0, st, P, T);            \
+    } while (0)
+                if (cull && !count) RT_WALK_CASE(true, false);
+                else if (cull && count) RT_WALK_CASE(true, true);
+                else if (!cull && !count) RT_WALK_CASE(false, false);
+                else RT_WALK_CASE(false, true);
+#undef RT_WALK_CASE
+            } else {
+                launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
+            }
             P.hits = static_cast<const HitRec*>(w.d_hits);
         } else {
             P.hits = nullptr;
@@ -2463,6 +2502,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
         stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
         stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;
+        stats->pipeline = !w.lastWasWavefront ? RT_PIPELINE_DEPTH_FIRST : (w.lastRounds ? RT_PIPELINE_ROUNDS : RT_PIPELINE_PERSISTENT);
         if (w.lastWasWavefront && !w.fallSlots.empty()) {
             const uint32_t lo = w.fallSlots.front(), hi = w.fallSlots.back();
             std::vector<uint32_t> c(hi - lo + 1);

@@ -545,7 +545,9 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
 // list of round r+1.  Every round therefore runs dense waves, however uneven the pixels' chains are.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFrameDwords = 20;                                   // 80 B per pending glossy loop
-constexpr int kStateDwords = 16 + RT_MAX_RAY_DEPTH * kFrameDwords; // 544 B
+constexpr int kPassDwords = 12;                                    // 48 B per pending pass-through ray: origin, direction, weight, flag
+constexpr int kPassOff = RT_MAX_RAY_DEPTH * kFrameDwords;          // the pass records follow the loop frames
+constexpr int kStateDwords = 16 + RT_MAX_RAY_DEPTH * (kFrameDwords + kPassDwords); // 832 B
 enum PathStep : int { PS_DONE = 0, PS_TRACE = 1, PS_HIT, PS_GLOSSY, PS_POP, PS_BATCH };
 
 struct PathLane {
@@ -733,6 +735,8 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
     do {
         bool wantShade = false, wantLeaf = false, wantFrames = false, wantBatch = false, wantConsume = false;
         bool openLoop = false; // push a glossy frame after this pass's shade task has been appended
+        bool openPass = false; // the frame (a loop's, or one of its own) also holds a pending pass-through ray
+        vec3 passW = splat(0.0f);
         uint32_t hitMask = 0, opensMask = 0, nHits = 0, nOpened = 0; // of a batch whose candidates are back (PS_BATCH)
         constexpr uint32_t kMaxN = 5; // N (N + 1) / 2 <= kMaxBatchRays
         while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames && !wantBatch && !wantConsume) {
@@ -762,9 +766,20 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 wantShade = true; // the hit's direct light: deferred to the shade kernel
                 for (uint32_t k = 0; k < P.lightDraws; k++) (void)sampler_next(L.smp); // the light loop's own draws
                 L.state = PS_POP;
-                if (L.depth < RT_MAX_RAY_DEPTH && F.enableReflections) {
+                if (L.depth < RT_MAX_RAY_DEPTH && (F.enableReflections || F.enableTransparency)) {
                     const Mat m = load_material(S, h.mesh, h.isSphere);
-                    const bool reflective = (m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f);
+                    // renderRayTransparentComponent (src/recursive.cpp:155-163): hitColor * (1 - transparency) + passColor *
+                    // transparency, once the reflection has returned.  As weights: everything this hit adds itself (direct
+                    // light, reflection subtree) counts (1 - transparency) times, the pass-through subtree transparency times.
+                    const bool passes = F.enableTransparency && m.transparency != 1.f;
+                    vec3 Wd = L.curW;
+                    if (passes) {
+                        Wd = L.curW * (1.f - m.transparency);
+                        passW = L.curW * m.transparency;
+                        st.W[0] = Wd.x, st.W[1] = Wd.y, st.W[2] = Wd.z;
+                    }
+                    const bool reflective = F.enableReflections && ((m.ks.x != 0.0f) || (m.ks.y != 0.0f) || (m.ks.z != 0.0f));
+                    bool spawned = false;
                     if (reflective) {
                         // generateReflectionRay (src/recursive.cpp:91-103)
                         vec3 rorg = p;
@@ -772,17 +787,29 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                         rorg = rorg + 0.00001f * rdir;
                         if (!F.enableGlossyReflection) { // renderRaySpecularComponent: weight * ks
                             L.to = rorg, L.td = rdir;
-                            L.curW = L.curW * m.ks;
+                            L.curW = Wd * m.ks;
                             L.depth++;
                             cSecondary++;
                             L.state = PS_TRACE;
+                            openPass = passes; // the pass-through ray waits in a frame until this chain has returned
+                            spawned = true;
                         } else if (F.numGlossySamples > 0) { // renderRayGlossyComponent (src/extra.cpp:464-508)
                             // the frame is parked in the task record's neighbours until storage exists
                             L.to = rorg, L.td = rdir; // reused as scratch: reflection ray of the new loop
                             L.tt = 0.5f / m.shininess;
+                            L.curW = Wd;
                             openLoop = true;
+                            openPass = passes;
+                            spawned = true;
                             // ks and normal are re-read from st / material when the frame is written
                         }
+                    }
+                    if (!spawned && passes) { // generatePassthroughRay (src/recursive.cpp:112-123): nothing else is pending at this hit
+                        L.to = p + 0.00001f * L.td;
+                        L.curW = passW;
+                        L.depth++;
+                        cSecondary++;
+                        L.state = PS_TRACE;
                     }
                 }
                 break;
@@ -833,9 +860,18 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     break;
                 }
                 frames[L.loopDepth * kFrameDwords + 16] = __uint_as_float(i);
-                if (!launched) { // loop finished: resume the enclosing loop
-                    L.loopDepth = enclosing;
+                if (!launched) { // loop finished: the hit's pass-through ray if one waits, else resume the enclosing loop
+                    const float* pr = frames + kPassOff + L.loopDepth * kPassDwords;
                     L.state = PS_POP;
+                    if (F.enableTransparency && pr[9] != 0.0f) {
+                        const float4* pq = reinterpret_cast<const float4*>(pr);
+                        const float4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                        L.to = make3(p0.x, p0.y, p0.z), L.td = make3(p0.w, p1.x, p1.y), L.curW = make3(p1.z, p1.w, p2.x);
+                        L.depth = L.loopDepth + 1;
+                        cSecondary++;
+                        L.state = PS_TRACE;
+                    }
+                    L.loopDepth = enclosing;
                 }
                 break;
             }
@@ -894,7 +930,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         }
         // ---- append the tasks produced in this pass ----
         if (__ballot(wantShade) != 0ull) {
-            const bool pushFrame = wantShade && openLoop;
+            const bool pushFrame = wantShade && (openLoop || openPass);
             if (wantShade) {
                 if (shadeSlot != 0xffffffffu) {
                     const float4* src = reinterpret_cast<const float4*>(&st);
@@ -907,15 +943,29 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             // lanes that open a glossy loop need frame storage; allocate for those that have none yet
             if (__ballot(pushFrame && frames == nullptr) != 0ull) allocFrames(pushFrame && frames == nullptr);
             if (pushFrame) {
-                const Mat m = load_material(S, st.matInfo & 0x7fffffffu, (st.matInfo >> 31) != 0);
-                float4* fq = reinterpret_cast<float4*>(frames + L.depth * kFrameDwords);
-                fq[0] = make_float4(L.curW.x, L.curW.y, L.curW.z, L.to.x);
-                fq[1] = make_float4(L.to.y, L.to.z, L.td.x, L.td.y);
-                fq[2] = make_float4(L.td.z, st.nx, st.ny, st.nz);
-                fq[3] = make_float4(m.ks.x, m.ks.y, m.ks.z, L.tt);
-                fq[4] = make_float4(__uint_as_float(0u), __uint_as_float((uint32_t)(L.loopDepth + 1)), 0.0f, 0.0f);
-                L.loopDepth = L.depth;
-                L.state = PS_GLOSSY;
+                const int level = openLoop ? L.depth : L.depth - 1; // rayDepth of the hit (a specular chain has already moved on)
+                float4* fq = reinterpret_cast<float4*>(frames + level * kFrameDwords);
+                if (openLoop) {
+                    const Mat m = load_material(S, st.matInfo & 0x7fffffffu, (st.matInfo >> 31) != 0);
+                    fq[0] = make_float4(L.curW.x, L.curW.y, L.curW.z, L.to.x);
+                    fq[1] = make_float4(L.to.y, L.to.z, L.td.x, L.td.y);
+                    fq[2] = make_float4(L.td.z, st.nx, st.ny, st.nz);
+                    fq[3] = make_float4(m.ks.x, m.ks.y, m.ks.z, L.tt);
+                    fq[4] = make_float4(__uint_as_float(0u), __uint_as_float((uint32_t)(L.loopDepth + 1)), 0.0f, 0.0f);
+                    L.state = PS_GLOSSY;
+                } else { // no loop at this hit: a frame whose samples are all taken
+                    fq[4] = make_float4(__uint_as_float(0xffffffffu), __uint_as_float((uint32_t)(L.loopDepth + 1)), 0.0f, 0.0f);
+                }
+                if (F.enableTransparency) {
+                    float4* pq = reinterpret_cast<float4*>(frames + kPassOff + level * kPassDwords);
+                    // generatePassthroughRay (src/recursive.cpp:112-123): from just past the hit point, same direction
+                    const vec3 d = make3(st.dx, st.dy, st.dz);
+                    const vec3 porg = make3(st.px, st.py, st.pz) + 0.00001f * d;
+                    pq[0] = make_float4(porg.x, porg.y, porg.z, d.x);
+                    pq[1] = make_float4(d.y, d.z, passW.x, passW.y);
+                    pq[2] = make_float4(passW.z, openPass ? 1.0f : 0.0f, 0.0f, 0.0f);
+                }
+                L.loopDepth = level;
             }
         }
         if (wantLeaf) {
@@ -1653,6 +1703,117 @@ __global__ __launch_bounds__(kBlock) void shadow_gen_kernel(const WaveParams P)
     flush_counters(P.stats, lane, 0, cShadow, 0, tc, 0, 0);
 }
 
+// visibilityOfLightSampleTransparency (src/light.cpp:107-136) for the shadow rays of the chunk: a lane follows its light
+// sample from the light through every surface on the way to the shaded point; each surface tints and dims what gets past
+// it, and what reached the LAST surface met is what the sample contributes.  The walk is a chain of closest-hit queries
+// in the caller's tree, each starting just past the previous hit.  The reference's walk ends only when a surface is met
+// within 1e-5 of the shaded point or nothing is hit; where it would oscillate around the shaded surface for ever, this
+// one stops after kMaxShadowSegments surfaces.  The colour that arrives replaces the ray's origin in its record.
+template <bool CULL, bool COUNT, int STACK>
+__global__ __launch_bounds__(kBlock) void shadow_walk_kernel(const WaveParams P, const TraceParams Q)
+{
+    __shared__ uint32_t s_stack[2 * STACK * kBlock];
+    uint32_t* const stack = s_stack + threadIdx.x;
+    const SceneView& S = Q.S;
+    const int lane = threadIdx.x & 63;
+    const uint32_t have = min(P.qCount[0], P.shadeCap);
+    const uint32_t tasks = have > P.chunkBase ? min(have - P.chunkBase, P.chunkTasks) : 0u;
+    const uint32_t total = tasks * P.raysPerTask;
+    TraceCounters tc { 0, 0, 0 };
+    uint32_t cShadow = 0;
+    const uint32_t gridLanes = gridDim.x * kBlock;
+    bool has = false, exhausted = total <= gridLanes, first = true;
+    uint32_t idx = 0, chunkNext = 0, chunkEnd = 0, segments = 0;
+    vec3 ip = splat(0.0f), incoming = splat(0.0f), prev = splat(0.0f), org = splat(0.0f);
+    TraceLane T;
+    trace_lane_clear(T);
+    if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later
+    // one surface met (or none): true when the walk goes on with another query
+    auto walk_step = [&]() -> bool {
+        const bool intersects = T.tri != kNoHit;
+        const bool finalRayT = fabsf(T.t - length(ip - org)) <= 1e-5f;
+        if (intersects) {
+            const bool sph = T.tri >= kSphereBase;
+            const Mat hm = load_material(S, sph ? T.tri - kSphereBase : S.triAttr[T.tri].meshID, sph);
+            prev = incoming;
+            incoming = incoming * hm.kd * (1.0f - hm.transparency);
+            org = org + (T.t + 1e-6f) * T.R.d;
+        }
+        return intersects && !finalRayT && segments < kMaxShadowSegments;
+    };
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd)) {
+            uint32_t next = 0xffffffffu;
+            if (first) {
+                next = blockIdx.x * kBlock + threadIdx.x;
+            } else {
+                if (chunkNext == chunkEnd) { // !exhausted here
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(Q.fetch, kLaneChunk);
+                    base = __shfl(base, 0) + gridLanes;
+                    exhausted = base + kLaneChunk >= total;
+                    chunkNext = min(base, total), chunkEnd = min(base + kLaneChunk, total);
+                }
+                const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t avail = chunkEnd - chunkNext, n = (uint32_t)__popcll(idle);
+                if (rank < avail) next = chunkNext + rank;
+                chunkNext += min(n, avail);
+            }
+            first = false;
+            if (!has) idx = next;
+            if (!has && idx < total) {
+                const float4* q = reinterpret_cast<const float4*>(P.shadowRays + idx);
+                const float4 a = q[0], b = q[1];
+                if (a.w < 0.0f) { // the slot of an unused task: nothing to follow
+                } else {
+                    // the shaded point and the sample's colour, as shadow_gen_kernel saw them
+                    const uint32_t task = idx / P.raysPerTask, j = idx - task * P.raysPerTask;
+                    const float4* tq = reinterpret_cast<const float4*>(P.shadeQ + P.chunkBase + task);
+                    const float4 ta = tq[0], tb = tq[1], tcw = tq[2];
+                    ip = make3(tb.w, tcw.x, tcw.y);
+                    for_each_light_sample(S, P.F, __float_as_uint(ta.z), [&](const uint32_t jj, int, bool, const vec3, const vec3 lcol) {
+                        if (jj == j) incoming = prev = lcol;
+                    });
+                    org = make3(a.x, a.y, a.z);
+                    segments = 1;
+                    for (;;) { // queries that end at the root box are answered on the spot
+                        has = trace_begin<COUNT>(S, Q.useBvh != 0, T, org, segments == 1 ? make3(b.x, b.y, b.z) : normalize(ip - org), FLT_MAX, tc);
+                        if (has) break;
+                        if (!walk_step()) break;
+                        segments++, cShadow++;
+                    }
+                    if (!has) {
+                        float4* o = reinterpret_cast<float4*>(P.shadowRays + idx);
+                        o[0] = make_float4(prev.x, prev.y, prev.z, 0.0f);
+                    }
+                }
+            }
+        }
+        if (__ballot(has) == 0ull) {
+            if (exhausted && chunkNext == chunkEnd) break;
+            continue;
+        }
+#pragma unroll 1
+        for (int it = 0; it < kStepsPerCheck; it++) {
+            const bool ended = trace_wave_step<CULL, COUNT, STACK, false>(S, has, T, stack, tc);
+            if (ended) {
+                has = false;
+                while (walk_step()) {
+                    segments++, cShadow++;
+                    has = trace_begin<COUNT>(S, Q.useBvh != 0, T, org, normalize(ip - org), FLT_MAX, tc);
+                    if (has) break;
+                }
+                if (!has) {
+                    float4* o = reinterpret_cast<float4*>(P.shadowRays + idx);
+                    o[0] = make_float4(prev.x, prev.y, prev.z, 0.0f);
+                }
+            }
+        }
+    }
+    flush_counters(P.stats, lane, 0, cShadow, 0, tc, 0, 0);
+}
+
 // computeLightContribution (src/light.cpp:262-276) for the shade tasks of the chunk, with the shadow
 // queries answered by P.hits (null when shadows are off).
 __global__ __launch_bounds__(kBlock) void shade_logic_kernel(const WaveParams P)
@@ -1674,7 +1835,10 @@ __global__ __launch_bounds__(kBlock) void shade_logic_kernel(const WaveParams P)
         vec3 Lo = splat(0.0f), areaAcc = splat(0.0f);
         for_each_light_sample(S, F, __float_as_uint(a.z), [&](const uint32_t j, const int type, const bool last, const vec3 lpos, const vec3 lcol) {
             vec3 visible = lcol;
-            if (hits) {
+            if (hits && F.enableTransparency) { // what shadow_walk_kernel left in the sample's ray record
+                const float4 v = reinterpret_cast<const float4*>(P.shadowRays + (size_t)i * P.raysPerTask + j)[0];
+                visible = make3(v.x, v.y, v.z);
+            } else if (hits) {
                 const HitRec h = hits[j];
                 const bool expected = fabsf(h.t - length(p - lpos)) <= 5e-4f;
                 if (!(h.tri != kNoHit && expected)) visible = splat(0.0f);

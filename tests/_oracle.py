@@ -62,6 +62,7 @@ def lib():
     L.orc_scene_create.restype = C.c_void_p
     L.orc_scene_create.argtypes = [u32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]
     L.orc_scene_destroy.argtypes = [C.c_void_p]
+    L.orc_set_shadow_walk_cap.argtypes = [C.c_int]
     for n in ("orc_bvh_num_nodes", "orc_bvh_num_prims", "orc_bvh_num_levels", "orc_bvh_num_leaves"):
         getattr(L, n).restype = C.c_uint32
         getattr(L, n).argtypes = [C.c_void_p]
