@@ -118,11 +118,17 @@ def main():
     ap.add_argument("--obj", default=None, help="Wavefront OBJ to use where a workload names the dragon")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cull", action="store_true", help="traverse exactly as the reference (no distance culling)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="frames queued at once, each on its own stream (1..4)")
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="frames queued at once, each on its own stream (1..8)")
+    ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0: leave the environment's value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
     args = ap.parse_args()
 
+    # Streams map onto the HIP runtime's hardware queues, 4 per process by default: with 4 frame streams next to the null
+    # stream and the copy back, two streams share a queue and their launches wait for each other.  Must be set before the
+    # runtime starts.
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     import torch
     import torch.distributed as dist
     from raytracer_amd import api
@@ -161,7 +167,7 @@ def main():
     region = api.Region(8, rank, world)
     flags = api.RT_RENDER_NO_CULL if args.no_cull else 0
 
-    F = max(1, min(4, args.frames_in_flight))
+    F = max(1, min(8, args.frames_in_flight))
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     frames = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
@@ -199,10 +205,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(F):  # set-up, not a step: every stream's frame buffers are allocated by its first frame
+        step(i, cams[i % len(cams)] if cams else None)
+    barrier()
     for i in range(args.warmup):
         step(i, cams[i % len(cams)] if cams else None)
     barrier()
-    stats = scene.sync(streams[(args.warmup - 1) % F].cuda_stream if args.warmup else streams[0].cuda_stream)  # this rank's share of one frame
+    stats = scene.sync(streams[0].cuda_stream)  # this rank's share of one frame
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, cams[i] if cams else None)
@@ -284,6 +293,7 @@ def main():
             "config": {"workload": args.workload, "description": wl["desc"], "width": W, "height": H,
                        "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
                        "rays_per_frame": int(rays_frame), "frames_in_flight": F,
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "step": "rt_render" + (" + stripe all-gather" if world > 1 else "") + " + rt_bloom + frame copy to pinned host memory",
                        "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-gather" if world > 1 else ""),
                        "culling": not args.no_cull},

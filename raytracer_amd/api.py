@@ -149,8 +149,8 @@ class Bvh:
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().rt_bvh_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:  # at interpreter exit the module may already be torn down
+            _lib.rt_bvh_destroy(self.h)
             self.h = None
 
     @property
@@ -231,8 +231,8 @@ class Scene:
         check(lib().rt_scene_set_texture(self.h, int(material), _p(a, f32p), a.shape[1], a.shape[0]))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().rt_scene_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.rt_scene_destroy(self.h)
             self.h = None
 
     def render_image(self, cam, features, W, H, start_depth=0, flags=0, want_ids=True):

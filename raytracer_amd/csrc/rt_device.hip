@@ -94,6 +94,9 @@ struct rt_scene {
     uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
     uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
+    uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
+                                    // RT_AMD_NO_BATCH: one child per round; at most 5)
+    bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
     uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
@@ -1555,7 +1558,7 @@ void free_workspace(Workspace* w)
     delete w;
 }
 
-constexpr size_t kMaxWorkspaces = 4;
+constexpr size_t kMaxWorkspaces = 8;
 // The buffers of the frames queued on `stream`: frames on one stream share a set (they run one after the other anyway), a
 // stream not seen before gets its own, and beyond kMaxWorkspaces streams the set unused for longest is taken over once the
 // frames of its stream have finished.  Null (with the error set) when nothing can be allocated.
@@ -1576,7 +1579,8 @@ Workspace* workspace_for(rt_scene* scene, hipStream_t stream, const bool create)
             return nullptr;
         }
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&w->d_stats), kStatCopies * kStatStride * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(w->d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long));
+        // (cleared by every rt_render on the frame's own stream: a memset on the null stream is not ordered with the
+        // non-blocking streams frames are queued on, and may land after their first kernels)
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&w->d_work), 256);
         if (e != hipSuccess) {
             rt::set_error("device allocation of a frame's counters failed: %s", hipGetErrorString(e));
@@ -1725,6 +1729,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (e == hipSuccess) e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // frames run on streams the null stream's memset is not ordered with
     s->texturePixels.assign(nMaterials, nullptr);
     if (e != hipSuccess) {
         rt::set_error("rt_scene_create: device allocation/upload of %zu bytes failed: %s", total, hipGetErrorString(e));
@@ -1770,6 +1775,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s\n",
                 nTris, nPairs, flat.maxDepth, nQPairs, qt.pairDepth, nQNodes, qt.maxDepth, qt.usable ? "" : " (not used)");
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_BATCH_WINDOW")) s->batchWindow = (uint32_t)std::min(5, std::max(0, atoi(e)));
+    if (getenv("RT_AMD_NO_BATCH")) s->batchWindow = 0;
+    s->noPlan = getenv("RT_AMD_NO_PLAN") != nullptr, s->scatter = getenv("RT_AMD_SCATTER") != nullptr;
+    s->verbose = getenv("RT_AMD_VERBOSE") != nullptr;
     if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
@@ -1937,8 +1946,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         w.d_accum = nullptr, w.d_nonfinite = nullptr, w.accumPixels = 0;
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_accum), px * 3 * sizeof(long long)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_nonfinite), px * sizeof(uint32_t)));
-        RT_HIP(hipMemset(w.d_accum, 0, px * 3 * sizeof(long long)));
-        RT_HIP(hipMemset(w.d_nonfinite, 0, px * sizeof(uint32_t)));
+        RT_HIP(hipMemsetAsync(w.d_accum, 0, px * 3 * sizeof(long long), st)); // on the frame's stream: ordered before its kernels
+        RT_HIP(hipMemsetAsync(w.d_nonfinite, 0, px * sizeof(uint32_t), st));
         w.accumPixels = px;
     }
     uint64_t want = (uint64_t)nWork * 8u;
@@ -1980,15 +1989,16 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count && !features->enableTransparency;
     const bool usePath = usePathGroup || usePathLane;
     // (rounds only) a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
-    uint32_t batchRays = 0;
+    uint32_t batchRays = 0, batchWindow = 0;
     if (!usePath) {
         bool area = false;
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
-        if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && N * (N + 1) / 2 <= kMaxBatchRays
-            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !features->enableTransparency
-            && !getenv("RT_AMD_NO_BATCH")) // a counting pass walks only the reference's rays
-            batchRays = N * (N + 1) / 2;
+        if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && scene->batchWindow >= 2
+            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !features->enableTransparency) { // a counting pass walks only the reference's rays
+            batchWindow = std::min(N, scene->batchWindow);
+            batchRays = batchWindow * (batchWindow + 1) / 2;
+        }
     }
     const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
     if (w.stateCap < nWork) {
@@ -2062,7 +2072,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         chain = 0;
         for (int l = 0; l < levels && chain < kMaxRounds; l++) {
             // the deepest level of a batched frame costs one round per PARENT ray, not one per ray
-            chain += (batchRays && l == levels - 1 && l > 0) ? term / (fan ? fan : 1) : term;
+            chain += (batchRays && l == levels - 1 && l > 0) ? term / (fan ? fan : 1) * ((fan + batchWindow - 1) / batchWindow) : term;
             term *= (fan ? fan : 1);
             if (!features->enableReflections) break;
         }
@@ -2103,7 +2113,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     P.states = w.d_states;
     P.pathRays = static_cast<RayRec*>(w.d_pathRays[0]), P.pathRaysIn = nullptr;
     P.rayCap = (uint32_t)(w.pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : w.pathRayCap);
-    P.batchRays = batchRays;
+    P.batchRays = batchRays, P.batchWindow = batchWindow;
     P.hits = static_cast<const HitRec*>(w.d_hits);
     P.shadowRays = static_cast<RayRec*>(w.d_shadowRays);
     P.chunkBase = 0, P.chunkTasks = chunkTasks, P.raysPerTask = raysPerTask;
@@ -2119,7 +2129,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
         mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
     }
-    const bool planned = !count && key == w.planKey && w.roundRays.size() == rounds && !getenv("RT_AMD_NO_PLAN");
+    const bool planned = !count && key == w.planKey && w.roundRays.size() == rounds && !scene->noPlan;
     w.lastKey = key, w.lastRounds = usePath ? 0u : rounds;
 
     TraceParams T;
@@ -2230,7 +2240,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         const uint32_t N = features->numGlossySamples ? features->numGlossySamples : 1u;
         K.shadeChunk = 256u, K.leafChunk = N * 64u;
         K.advanceAt = scene->advanceAt, K.advanceEvery = scene->advanceEvery;
-        K.scatter = getenv("RT_AMD_SCATTER") ? 1u : 0u;
+        K.scatter = scene->scatter ? 1u : 0u;
         K.contList = nullptr, K.contCount = nullptr, K.linkBudget = 0, K.minLanes = 0;
         const uint32_t pathGrid = (uint32_t)scene->numCUs * scene->pathBlocksPerCU;
         const bool query = features->enableAccelStructure && scene->queryView.cert != nullptr && !(flags & RT_RENDER_REFERENCE_TREE);
@@ -2337,7 +2347,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
         P.activeRayIn = w.d_activeRay[(r - 1) & 1], P.activeRayOut = w.d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
-        hipLaunchKernelGGL(path_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
+        if (features->enableTransparency) hipLaunchKernelGGL(path_logic_kernel<true>, dim3(taskGrid), dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL(path_logic_kernel<false>, dim3(taskGrid), dim3(kBlock), 0, st, P);
     }
     // what the batched loops left for later: their children's hit records and the grandchildren's rays
     if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
@@ -2533,7 +2544,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             return RT_ERR_LIMIT;
         }
     }
-    if (w.lastWasWavefront && !w.sliceSlots.empty() && getenv("RT_AMD_VERBOSE")) {
+    if (w.lastWasWavefront && !w.sliceSlots.empty() && scene->verbose) {
         fprintf(stderr, "rt_amd: pixels set aside by the slices of the path stage:");
         for (uint32_t slot : w.sliceSlots) {
             uint32_t v = 0;
@@ -2548,7 +2559,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
         RT_HIP(hipMemcpy(&w.roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
         if (n > 1) RT_HIP(hipMemcpy(&w.roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
         w.planKey = w.lastKey;
-        if (getenv("RT_AMD_VERBOSE")) { // rays traced by the path rounds (candidate batches included), round by round
+        if (scene->verbose) { // rays traced by the path rounds (candidate batches included), round by round
             unsigned long long sum = 0;
             for (uint32_t v : w.roundRays) sum += v;
             fprintf(stderr, "rt_amd: %u path rounds traced %llu rays:", n, sum);

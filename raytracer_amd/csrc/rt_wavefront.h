@@ -88,7 +88,8 @@ struct WaveParams {
     const uint32_t* activeRayIn;
     uint32_t* activeRayOut;
     uint32_t rayCap;          // capacity of pathRays
-    uint32_t batchRays;       // N(N+1)/2 candidate rays of a batched glossy loop (0 = loops are walked one child per round)
+    uint32_t batchRays;       // most candidate rays of one batch of a glossy loop's children, w(w+1)/2 (0 = loops are walked one child per round)
+    uint32_t batchWindow;     // w: children of such a loop traced per round
     const HitRec* hits;       // hits of the rays this kernel consumes
     RayRec* shadowRays;       // shadow_gen output, raysPerTask per shade task of the chunk
     uint32_t chunkBase, chunkTasks, raysPerTask;
@@ -722,7 +723,8 @@ constexpr uint32_t kHolePixel = 0xffffffffu; // a reserved but unused ShadeTask 
 // of its pixel (PS_DONE), appending the shade / leaf tasks met on the way.  Every thread of the workgroup must call it
 // (the passes are workgroup-convergent: queue slots are reserved per workgroup).  s_n: 12 words, s_base: 3 words of LDS.
 // frames: this lane's frame storage in HBM (null while the lane has none: lanes allocate lazily).
-template <typename AllocFn>
+// TRANSP: the frame has transparency enabled (pass-through rays exist); compiled apart so that frames without it do not carry its registers
+template <bool TRANSP, typename AllocFn>
 __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, float*& frames, AllocFn&& allocFrames, const int lane,
                                               uint32_t& cPrimary, uint32_t& cSecondary, uint32_t& cDrop, uint32_t* s_n, uint32_t* s_base)
 {
@@ -738,6 +740,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         bool openPass = false; // the frame (a loop's, or one of its own) also holds a pending pass-through ray
         vec3 passW = splat(0.0f);
         uint32_t hitMask = 0, opensMask = 0, nHits = 0, nOpened = 0; // of a batch whose candidates are back (PS_BATCH)
+        uint32_t batchKids = 0; // children of the loop in the batch being emitted / consumed
         constexpr uint32_t kMaxN = 5; // N (N + 1) / 2 <= kMaxBatchRays
         while (L.state > PS_TRACE && !wantShade && !wantLeaf && !wantFrames && !wantBatch && !wantConsume) {
             switch (L.state) {
@@ -766,12 +769,12 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 wantShade = true; // the hit's direct light: deferred to the shade kernel
                 for (uint32_t k = 0; k < P.lightDraws; k++) (void)sampler_next(L.smp); // the light loop's own draws
                 L.state = PS_POP;
-                if (L.depth < RT_MAX_RAY_DEPTH && (F.enableReflections || F.enableTransparency)) {
+                if (L.depth < RT_MAX_RAY_DEPTH && (F.enableReflections || (TRANSP && F.enableTransparency))) {
                     const Mat m = load_material(S, h.mesh, h.isSphere);
                     // renderRayTransparentComponent (src/recursive.cpp:155-163): hitColor * (1 - transparency) + passColor *
                     // transparency, once the reflection has returned.  As weights: everything this hit adds itself (direct
                     // light, reflection subtree) counts (1 - transparency) times, the pass-through subtree transparency times.
-                    const bool passes = F.enableTransparency && m.transparency != 1.f;
+                    const bool passes = (TRANSP && F.enableTransparency) && m.transparency != 1.f;
                     vec3 Wd = L.curW;
                     if (passes) {
                         Wd = L.curW * (1.f - m.transparency);
@@ -824,8 +827,9 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
                 vec3 w, u, v;
                 ortho_basis(rdir, w, u, v);
-                if (P.batchRays != 0 && i == 0 && L.loopDepth == RT_MAX_RAY_DEPTH - 2) {
+                if (P.batchRays != 0 && L.loopDepth == RT_MAX_RAY_DEPTH - 2 && i + 2 <= F.numGlossySamples) {
                     wantBatch = true; // emitted below, once the wave has reserved the rays
+                    batchKids = min(P.batchWindow, F.numGlossySamples - i);
                     break;
                 }
                 bool launched = false;
@@ -863,7 +867,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 if (!launched) { // loop finished: the hit's pass-through ray if one waits, else resume the enclosing loop
                     const float* pr = frames + kPassOff + L.loopDepth * kPassDwords;
                     L.state = PS_POP;
-                    if (F.enableTransparency && pr[9] != 0.0f) {
+                    if ((TRANSP && F.enableTransparency) && pr[9] != 0.0f) {
                         const float4* pq = reinterpret_cast<const float4*>(pr);
                         const float4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
                         L.to = make3(p0.x, p0.y, p0.z), L.td = make3(p0.w, p1.x, p1.y), L.curW = make3(p1.z, p1.w, p2.x);
@@ -894,10 +898,10 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 // The traced candidates are back.  Only the sampler's progress is needed before the pixel's next ray can
                 // start, and it depends on which candidates hit a reflecting surface: that bit per candidate, all loads
                 // in flight together.
-                const uint32_t N = F.numGlossySamples;
+                batchKids = L.nRays == 3 ? 2u : (L.nRays == 6 ? 3u : (L.nRays == 10 ? 4u : 5u)); // nRays = kids (kids + 1) / 2
                 uint32_t ctri[kMaxBatchRays], cmesh[kMaxBatchRays];
 #pragma unroll
-                for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < P.batchRays) ? P.hits[L.rayBase + c].tri : kNoHit;
+                for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < L.nRays) ? P.hits[L.rayBase + c].tri : kNoHit;
 #pragma unroll
                 for (uint32_t c = 0; c < kMaxBatchRays; c++) cmesh[c] = (ctri[c] < kSphereBase) ? S.triAttr[ctri[c]].meshID : 0u;
 #pragma unroll
@@ -912,7 +916,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
 #pragma unroll
                 for (uint32_t i = 0; i < kMaxN; i++) {
                     const uint32_t k = i * (i + 1) / 2 + nOpened;
-                    if (i < N) nHits += (hitMask >> k) & 1u, nOpened += (opensMask >> k) & 1u;
+                    if (i < batchKids) nHits += (hitMask >> k) & 1u, nOpened += (opensMask >> k) & 1u;
                 }
                 wantConsume = true;
                 break;
@@ -925,7 +929,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         {
             const uint32_t N = F.numGlossySamples;
             reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? nHits : 0u), P.qCount + 1, P.leafCap,
-                           wantLeaf ? 1u : (wantConsume ? N * nOpened : 0u), P.rayCountOut, P.rayCap, wantBatch ? P.batchRays : 0u, lane, s_n,
+                           wantLeaf ? 1u : (wantConsume ? N * nOpened : 0u), P.rayCountOut, P.rayCap, wantBatch ? batchKids * (batchKids + 1) / 2 : 0u, lane, s_n,
                            s_base, shadeSlot, leafSlot, raySlot);
         }
         // ---- append the tasks produced in this pass ----
@@ -956,7 +960,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 } else { // no loop at this hit: a frame whose samples are all taken
                     fq[4] = make_float4(__uint_as_float(0xffffffffu), __uint_as_float((uint32_t)(L.loopDepth + 1)), 0.0f, 0.0f);
                 }
-                if (F.enableTransparency) {
+                if ((TRANSP && F.enableTransparency)) {
                     float4* pq = reinterpret_cast<float4*>(frames + kPassOff + level * kPassDwords);
                     // generatePassthroughRay (src/recursive.cpp:112-123): from just past the hit point, same direction
                     const vec3 d = make3(st.dx, st.dy, st.dz);
@@ -978,8 +982,9 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             }
         }
         // ---- batched glossy loop: the loop's children are the last rays that can spawn anything, and each of
-        // them either consumes no further draws or exactly 2N (its own loop, whose children are deferred).  Child
-        // i therefore starts at one of i+1 known sampler offsets: trace a candidate for each, pick afterwards.
+        // them either consumes no further draws or exactly 2N (its own loop, whose children are deferred).  The
+        // a-th child of a batch therefore starts at one of a+1 known sampler offsets: trace a candidate for each, pick
+        // afterwards.  A batch holds the loop's next batchWindow children (the whole loop when the window allows).
         if (__ballot(wantBatch) != 0ull) {
             const uint32_t N = F.numGlossySamples;
             const uint32_t base = raySlot;
@@ -994,9 +999,9 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     const float radius = f3.w;
                     vec3 w, u, v;
                     ortho_basis(rdir, w, u, v);
-                    uint32_t rowSmp = L.smp; // offset 2i: no earlier child consumed anything
+                    uint32_t rowSmp = L.smp; // offset 2i: no earlier child of the batch consumed anything
                     uint32_t k = 0;
-                    for (uint32_t i = 0; i < N; i++) {
+                    for (uint32_t i = 0; i < batchKids; i++) {
                         uint32_t candSmp = rowSmp;
                         for (uint32_t c = 0; c <= i; c++, k++) {
                             uint32_t s2 = candSmp;
@@ -1008,7 +1013,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                         (void)sampler_next(rowSmp);
                         (void)sampler_next(rowSmp);
                     }
-                    L.nRays = P.batchRays;
+                    L.nRays = batchKids * (batchKids + 1) / 2;
                     L.rayBase = base;
                     L.state = PS_TRACE;
                 }
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
 #pragma unroll
                     for (uint32_t i = 0; i < kMaxN; i++) {
                         ksel[i] = i * (i + 1) / 2 + opened;
-                        if (i < N) opened += (opensMask >> ksel[i]) & 1u;
+                        if (i < batchKids) opened += (opensMask >> ksel[i]) & 1u;
                     }
                 }
                 // the samples' rays and hits; what the hits look like (normal, material) is worked out by shade_expand_kernel
@@ -1040,7 +1045,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 HitRec hr[kMaxN];
 #pragma unroll
                 for (uint32_t i = 0; i < kMaxN; i++) {
-                    if (i >= N) continue;
+                    if (i >= batchKids) continue;
                     const float4* rq = reinterpret_cast<const float4*>(P.pathRaysIn + L.rayBase + ksel[i]);
                     ra[i] = rq[0], rb[i] = rq[1];
                     hr[i] = P.hits[L.rayBase + ksel[i]];
@@ -1048,7 +1053,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 uint32_t nShade = 0, nLeaf = 0;
 #pragma unroll
                 for (uint32_t i = 0; i < kMaxN; i++) {
-                    if (i >= N) continue;
+                    if (i >= batchKids) continue;
                     (void)sampler_next(L.smp); // the sample's own two draws (its direction is in the stored ray)
                     (void)sampler_next(L.smp);
                     if (ra[i].w < 0.0f) continue; // rejected sample
@@ -1065,8 +1070,14 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     for (uint32_t z = 0; z < 2 * N; z++) (void)sampler_next(L.smp);
                 }
                 L.nRays = 1;
-                L.loopDepth = enclosing;
-                L.state = PS_POP;
+                const uint32_t nextChild = __float_as_uint(f4.x) + batchKids;
+                frames[L.loopDepth * kFrameDwords + 16] = __uint_as_float(nextChild);
+                if (nextChild < N) { // the loop's remaining children: another batch, or a last single child as an ordinary ray
+                    L.state = PS_GLOSSY;
+                } else {
+                    L.loopDepth = enclosing;
+                    L.state = PS_POP;
+                }
             }
         }
     } while (__syncthreads_or(L.state > PS_TRACE));
@@ -1162,6 +1173,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 }
 
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
+template <bool TRANSP>
 __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
 {
     __shared__ uint32_t s_n[12], s_base[3];
@@ -1192,7 +1204,7 @@ __global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
             }
         }
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
-        advance_lanes(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
+        advance_lanes<TRANSP>(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
         const bool active = (L.state == PS_TRACE);
         const bool single = active && L.nRays <= 1; // a batch reserved its rays when it was emitted
         uint32_t pos, rpos;
