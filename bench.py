@@ -212,11 +212,13 @@ def main():
         step(i, cams[i % len(cams)] if cams else None)
     barrier()
     stats = scene.sync(streams[0].cuda_stream)  # this rank's share of one frame
+    timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, cams[i] if cams else None)
+        step(i, cams[i] if cams else None, timed_ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
+    launch_ms_timed = float(np.mean([a.elapsed_time(b) for a, b in timed_ev]))  # one rt_render launch sequence among the others in flight
 
     # one frame with nothing else queued: its latency, and the duration of the rt_render launch sequence by itself
     # (events on the stream the launches run on)
@@ -252,17 +254,27 @@ def main():
     rays_frame = float(rays_rank[:3].sum().item())
 
     # Algorithmic bytes of rank 0's render launch (one rt_render = a fixed sequence of kernels on one stream, dominated by
-    # the trace kernels): per ray 64 B per node-pair step + 36 B per triangle test + 28 B ray in + 16 B hit out, plus 12 B
-    # per pixel written.  Steps and tests are counted by a counting pass of the walk the frame is timed with (distance
-    # culling on, the caller's tree); the same figure for the reference's own walk, which visits every box a ray enters
-    # (no culling), is reported beside it and is not the basis of `achieved`.
-    def counted(fl):
-        scene.render_device(cam, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region, flags=fl | api.RT_RENDER_COUNT_WORK, stream=s0)
+    # the trace kernels), counted by a counting pass of the frame as it is scheduled and timed: 128 B per 4-wide node of
+    # the query tree, 64 B per node pair (group launches, rays traced again in the caller's tree), 48 B per triangle test
+    # (plane, then two edge records), 28 B ray in + 16 B hit out per ray, 12 B per pixel written.  Candidate rays that are
+    # discarded and rays traced twice are in the node and triangle counts.  The same figure for the reference's own walk,
+    # which visits every box a ray enters (no culling, the caller's tree, 36 B per test), is reported beside it and is not
+    # the basis of `achieved`.
+    def counted(fl, schedule):
+        scene.render_device(cam, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region,
+                            flags=fl | (api.RT_RENDER_COUNT_SCHEDULE if schedule else api.RT_RENDER_COUNT_WORK), stream=s0)
         wk = scene.sync(s0)
-        return wk, 64.0 * wk.nodePairSteps + 36.0 * wk.triangleTests + 44.0 * wk.rays + 12.0 * wk.pixels
-    work, alg_bytes = counted(flags)
-    ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        tri_b = 48.0 if schedule else 36.0
+        return wk, 128.0 * wk.queryNodeSteps + 64.0 * wk.nodePairSteps + tri_b * wk.triangleTests + 44.0 * wk.rays + 12.0 * wk.pixels
+    try:
+        work, alg_bytes = counted(flags, True)
+        counted_what = "the frame as scheduled (query tree, candidate batches, second traces)"
+    except api.RtError:  # schedules without counters (a pixel per lane): the reference's rays in the caller's tree, culled
+        work, alg_bytes = counted(flags, False)
+        counted_what = "the reference's rays, culled walk in the caller's tree"
+    ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL, False)
+    achieved = alg_bytes * args.steps / elapsed / 1e9          # sustained over the timed region, frames in flight together
+    achieved_alone = alg_bytes / (kernel_ms * 1e-3) / 1e9      # one launch sequence with the GPU to itself
     traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
@@ -299,11 +311,15 @@ def main():
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "rt_render launch sequence of one frame alone (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "rt_render launch sequence of one frame (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
+                         "note": "achieved = algorithmic bytes of one launch sequence x steps / elapsed time of the timed region (frames_in_flight "
+                                 "sequences share the GPU); launch_ms_timed = mean duration of one sequence there, kernel_ms = alone, both from "
+                                 "events on the sequence's stream",
+                         "launch_ms_timed": launch_ms_timed, "kernel_ms": kernel_ms, "achieved_one_launch_alone": achieved_alone,
+                         "algorithmic_bytes_per_launch": alg_bytes, "counted": counted_what,
+                         "query_nodes_per_ray": work.queryNodeSteps / max(work.rays, 1),
                          "node_pairs_per_ray": work.nodePairSteps / max(work.rays, 1), "tri_tests_per_ray": work.triangleTests / max(work.rays, 1),
-                         "reference_walk": {"bytes_per_launch": ref_bytes, "gbs_over_kernel_ms": ref_bytes / (kernel_ms * 1e-3) / 1e9,
+                         "reference_walk": {"bytes_per_launch": ref_bytes,
                                             "node_pairs_per_ray": ref_work.nodePairSteps / max(ref_work.rays, 1),
                                             "tri_tests_per_ray": ref_work.triangleTests / max(ref_work.rays, 1)}},
         }

@@ -70,6 +70,7 @@ typedef struct rt_stats {
     uint64_t referenceTreeQueries; /* queries of the last wavefront frame that were traced again in the caller's tree
                                       because the query tree's result could not be proven equal (see RT_RENDER_REFERENCE_TREE) */
     uint64_t pipeline; /* which schedule rendered the frame: RT_PIPELINE_* */
+    uint64_t queryNodeSteps; /* RT_RENDER_COUNT_SCHEDULE: 4-wide nodes (128 B) visited in the library's query tree */
 } rt_stats;
 
 enum {
@@ -89,6 +90,11 @@ enum {
                                   for traversal cost alone, and accept what they find only when it is provably what
                                   the reference's walk (src/bvh.cpp:235-370) reports; the rest is traced again in
                                   the reference's tree.  Results are identical either way. */
+    RT_RENDER_COUNT_SCHEDULE = 32, /* flag: count the traversal work of the frame as it is scheduled by default - the query
+                                  tree's 4-wide nodes (queryNodeSteps), node pairs of either tree walked by several lanes
+                                  per ray or in the caller's tree (nodePairSteps), triangle tests, including candidate
+                                  rays that are later discarded and rays traced a second time.  RT_RENDER_COUNT_WORK
+                                  counts the reference's own walk instead and wins when both are set. */
     RT_RENDER_OVERLAPPED = 16, /* flag: the caller keeps several frames queued on different streams (frames are independent:
                                   main.cpp renders one per camera, src/main.cpp:515-526).  A scene holds one set of frame
                                   buffers per stream (up to four), so such frames overlap on the GPU; with this flag

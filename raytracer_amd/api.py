@@ -17,6 +17,7 @@ u32p = C.POINTER(C.c_uint32)
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT = range(6)
 RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_TREE, RT_RENDER_OVERLAPPED = 1, 2, 4, 8, 16
 RT_PIPELINE_DEPTH_FIRST, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
+RT_RENDER_COUNT_SCHEDULE = 32
 RT_BLOOM_STATIC_MAX_PIXELS = 1 << 21
 NO_HIT = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
@@ -55,7 +56,7 @@ class Region(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("primaryRays", "shadowRays", "secondaryRays", "nodePairSteps", "triangleTests",
-                                          "pixels", "stackOverflows", "referenceTreeQueries", "pipeline")]
+                                          "pixels", "stackOverflows", "referenceTreeQueries", "pipeline", "queryNodeSteps")]
 
     @property
     def rays(self):

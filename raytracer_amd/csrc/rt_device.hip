@@ -140,7 +140,7 @@ constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per ch
 constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is followed through (transparent shadows)
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
-enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_BIGVALUE, S_COUNT = 9 };
+enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_BIGVALUE, S_NODE4, S_COUNT = 10 };
 // The counters exist kStatCopies times, 256 B apart; a workgroup adds to the copy of its index and rt_sync sums them.
 // (Additions to one address are served one at a time, about 9 ns each: 8,000 waves ending together would wait 70 us.)
 constexpr uint32_t kStatCopies = 64, kStatStride = 32; // stride in counters
@@ -205,6 +205,7 @@ __device__ __forceinline__ bool box_test(const float lox, const float loy, const
 
 struct TraceCounters {
     uint32_t nodePairs, triTests, overflow;
+    uint32_t node4; // 4-wide nodes of the library's query tree
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1890,7 +1891,10 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     RT_HIP(hipMemsetAsync(w.d_work, 0, 256, st));
     w.lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
-    const bool cull = !(flags & RT_RENDER_NO_CULL), count = (flags & RT_RENDER_COUNT_WORK) != 0;
+    // countRef: the counters of the reference's walk (its rays, the caller's tree); countSchedule: the same counters, and
+    // the query tree's, for the frame exactly as it is scheduled by default (query tree, candidate batches, handed-over rays)
+    const bool countRef = (flags & RT_RENDER_COUNT_WORK) != 0, countSchedule = !countRef && (flags & RT_RENDER_COUNT_SCHEDULE) != 0;
+    const bool cull = !(flags & RT_RENDER_NO_CULL), count = countRef || countSchedule;
     // a frame that shares the GPU with others: one ray per lane (cheaper per ray, slower for the stage's longest ray) from fewer rays on
     const bool overlapped = (flags & RT_RENDER_OVERLAPPED) != 0;
     const uint32_t laneModeAbove = overlapped ? scene->laneModeAboveOverlapped : scene->laneModeAbove;
@@ -1966,7 +1970,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         w.leafCap = (uint32_t)want;
     }
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
-    const bool useQuery = groupOk && cull && !count && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
+    const bool useQuery = groupOk && cull && !countRef && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
         && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
     // The path stage - the rays whose outcome the pixel's sampler depends on - runs as one persistent launch in which a group
     // of lanes owns a pixel from its first ray to its last (path_kernel), or, without it, in frame-wide rounds.
@@ -1995,7 +1999,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
         if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && scene->batchWindow >= 2
-            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !count && !features->enableTransparency) { // a counting pass walks only the reference's rays
+            && startDepth <= RT_MAX_RAY_DEPTH - 2 && !countRef && !features->enableTransparency) { // a counting pass walks only the reference's rays
             batchWindow = std::min(N, scene->batchWindow);
             batchRays = batchWindow * (batchWindow + 1) / 2;
         }
@@ -2129,7 +2133,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
         mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
     }
-    const bool planned = !count && key == w.planKey && w.roundRays.size() == rounds && !scene->noPlan;
+    const bool planned = !countRef && key == w.planKey && w.roundRays.size() == rounds && !scene->noPlan;
     w.lastKey = key, w.lastRounds = usePath ? 0u : rounds;
 
     TraceParams T;
@@ -2153,8 +2157,15 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         T.S = query ? scene->queryView : scene->view;
         if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
-            if (groupLanes >= 8 && scene->quadTrace && scene->queryView.quadNodes) { // four lanes per ray instead
+            if (groupLanes >= 8 && scene->quadTrace && scene->queryView.quadNodes && !count) { // four lanes per ray instead
                 hipLaunchKernelGGL(quad_trace_kernel, dim3(std::max(1u, gridNow * 4u / groupLanes)), dim3(kBlock), 0, st, T);
+                return;
+            }
+            if (count) {
+                if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, true, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                else if (groupLanes == 16)
+                    hipLaunchKernelGGL((group_trace_kernel<true, true, 16, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                else hipLaunchKernelGGL((trace_kernel<true, true, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
                 return;
             }
             if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
@@ -2205,7 +2216,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         uint32_t* fallCount = w.d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
         T.runLo = laneModeAbove;
-        const uint32_t budget = (count || smallRound) ? 0u : (useQuery ? queryStepBudget : scene->stepBudget);
+        const uint32_t budget = (countRef || smallRound) ? 0u : (useQuery ? queryStepBudget : scene->stepBudget);
         T.stepBudget = budget, T.longCount = longCount;
         if (!smallRound) launch_one(1, useQuery); // the plan says few rays: the group launch takes them, however many there are
         T.runLo = 0, T.runHi = smallRound ? 0xffffffffu : laneModeAbove, T.stepBudget = 0, T.longCount = nullptr;
@@ -2511,7 +2522,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
 #endif
     if (stats) {
         stats->primaryRays = h[S_PRIMARY], stats->shadowRays = h[S_SHADOW], stats->secondaryRays = h[S_SECONDARY];
-        stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS];
+        stats->nodePairSteps = h[S_NODEPAIRS], stats->triangleTests = h[S_TRITESTS], stats->queryNodeSteps = h[S_NODE4];
         stats->pixels = h[S_PIXELS], stats->stackOverflows = h[S_OVERFLOW], stats->referenceTreeQueries = 0;
         stats->pipeline = !w.lastWasWavefront ? RT_PIPELINE_DEPTH_FIRST : (w.lastRounds ? RT_PIPELINE_ROUNDS : RT_PIPELINE_PERSISTENT);
         if (w.lastWasWavefront && !w.fallSlots.empty()) {

@@ -191,9 +191,9 @@ __device__ __forceinline__ void block_fetch2(uint32_t* counterA, const bool need
 __device__ __forceinline__ void flush_counters(unsigned long long* stats, const int lane, const uint32_t cPrimary, const uint32_t cShadow,
                                                const uint32_t cSecondary, const TraceCounters& tc, const uint32_t cPixels, const uint32_t cDrop)
 {
-    const uint32_t vals[8] = { cPrimary, cShadow, cSecondary, tc.nodePairs, tc.triTests, cPixels, tc.overflow, cDrop };
+    const uint32_t vals[10] = { cPrimary, cShadow, cSecondary, tc.nodePairs, tc.triTests, cPixels, tc.overflow, cDrop, 0u, tc.node4 };
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 10; i++) {
         unsigned long long v = vals[i];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0 && v) atomicAdd(stats + (blockIdx.x % kStatCopies) * kStatStride + i, v);
@@ -327,9 +327,10 @@ __device__ __forceinline__ void lane_node_step(const SceneView& S, TraceLane& T,
 }
 
 // The same for a query-tree launch: one 4-wide node, nearest child next, the others pushed farthest first.
-template <int STACK>
-__device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T, uint32_t* const stack)
+template <bool COUNT, int STACK>
+__device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
+    if (COUNT) tc.node4++;
     const Node4Hits h = node4_test(S.nodes4 + T.cur, T.R, T.t);
     if (h.key[0] == kMissKey) {
         lane_pop<true, STACK>(T, stack);
@@ -363,7 +364,7 @@ template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
     if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) {
-        if (QUERY) lane_node4_step<STACK>(S, T, stack);
+        if (QUERY) lane_node4_step<COUNT, STACK>(S, T, stack, tc);
         else lane_node_step<CULL, COUNT, STACK>(S, T, stack, tc);
     }
     if (has && T.cur != kTraversalDone && (T.cur & kLeafBit) && T.pend == 0) {
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
     const uint32_t gridLanes = gridDim.x * kBlock;
     bool has = false, exhausted = total <= gridLanes, first = true;
     uint32_t idx = 0, steps = 0, chunkNext = 0, chunkEnd = 0; // [chunkNext, chunkEnd): rays this wave holds (wave-uniform)
-    const uint32_t budget = COUNT ? 0u : P.stepBudget; // a counting pass walks every ray exactly once
+    const uint32_t budget = P.stepBudget; // (0 for a pass that counts the reference's walk: every ray is walked exactly once)
     TraceLane T;
     trace_lane_clear(T);
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later

@@ -100,6 +100,33 @@ def test_work_counters_match_reference_traversal():
     assert np.array_equal(rc["prim"], rg["prim"])
 
 
+@pytest.mark.parametrize("lane_mode_from", [None, 1])
+def test_counting_the_frame_as_scheduled_changes_nothing(lane_mode_from, monkeypatch):
+    """RT_RENDER_COUNT_SCHEDULE counts the traversal work of the default schedule (query tree, candidate batches) without
+    changing the frame; the reference's rays are the same, the work differs from the reference walk's.  Small stages walk
+    node pairs with several lanes per ray; with one ray per lane from the first ray on, the 4-wide nodes are walked."""
+    if lane_mode_from:
+        monkeypatch.setenv("RT_AMD_T1", str(lane_mode_from))
+    sc = scenes.dragon_standin(n_u=120, n_v=24)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)
+    cg, _ = both_cameras(384, 216)
+    r0 = g.render_image(cg, fg, 384, 216, start_depth=2)
+    r1 = g.render_image(cg, fg, 384, 216, start_depth=2, flags=api.RT_RENDER_COUNT_SCHEDULE)
+    r2 = g.render_image(cg, fg, 384, 216, start_depth=2, flags=api.RT_RENDER_COUNT_WORK)
+    assert np.array_equal(r0["rgb"].view(np.uint32), r1["rgb"].view(np.uint32))
+    assert r0["stats"].rays == r1["stats"].rays == r2["stats"].rays
+    s1, s2 = r1["stats"], r2["stats"]
+    print("as scheduled:", s1.queryNodeSteps, "4-wide nodes,", s1.nodePairSteps, "pairs,", s1.triangleTests, "tests; reference rays, culled:",
+          s2.nodePairSteps, "pairs,", s2.triangleTests, "tests")
+    assert r0["stats"].queryNodeSteps == 0 and s2.queryNodeSteps == 0
+    assert s1.triangleTests > 0 and s1.pipeline == api.RT_PIPELINE_ROUNDS
+    if lane_mode_from:
+        assert s1.queryNodeSteps > s1.rays
+    else:
+        assert s1.queryNodeSteps == 0 and s1.nodePairSteps > s1.rays
+
+
 @pytest.mark.parametrize("depth", [0, 2, 6])
 def test_full_depth_and_no_bounce(depth):
     g, o, _ = scene_pair("cornell")
