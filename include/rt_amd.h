@@ -235,6 +235,13 @@ int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked)
  * reference pairs, reference depth.  Returns RT_OK when the checks hold (usable = 0 when the reference's boxes are not
  * nested or too few triangles: queries then walk the caller's tree only). */
 int rt_selftest_query_tree(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, uint32_t info[8]);
+/* The same checks on a query tree whose hierarchy is built as rt_scene_create builds it: onDevice != 0 = on the current GPU
+ * (binned surface-area splits, one tree level per launch; replaces the role of the reference's host-side build,
+ * src/bvh.cpp:429-512, for the library's own tree - the reference-layout tree is still built on the host).  times (4 floats,
+ * may be NULL): hierarchy build ms (wall, incl. transfers), device launches ms, layout writing ms (host), 1 if the device
+ * build was used (0: it was not available and the host built the tree). */
+int rt_selftest_query_tree_built(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, int onDevice,
+                                 uint32_t info[8], float times[4]);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,7 @@ def lib():
     L.rt_intersect.argtypes = [vp, C.POINTER(Features), f32p, C.c_uint32, vp]
     L.rt_selftest_division.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rt_selftest_query_tree.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.rt_selftest_query_tree_built.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), f32p]
     _lib = L
     return L
 

@@ -3,6 +3,7 @@
 #include "rt_types.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -455,7 +456,7 @@ struct QueryBuilder {
 };
 } // namespace
 
-void build_query_tree(const FlatScene& flat, QueryTree& out)
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice)
 {
     out = QueryTree {};
     const uint32_t n = uint32_t(flat.triPlane.size());
@@ -471,19 +472,53 @@ void build_query_tree(const FlatScene& flat, QueryTree& out)
         qb.lo[i] = gmin(gmin(v0, v1), v2), qb.hi[i] = gmax(gmax(v0, v1), v2);
         qb.c[i] = (qb.lo[i] + qb.hi[i]) * 0.5f;
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
+    using clock = std::chrono::steady_clock;
+    auto ms_since = [](clock::time_point t0) { return std::chrono::duration<float, std::milli>(clock::now() - t0).count(); };
+    auto emit = [&](uint32_t root) {
+        out.nodes.clear(), out.pairs.clear();
+        out.maxDepth = 0, out.pairDepth = 1; // pairDepth counts levels of nodes as the flattener does: the root is level 1
+        out.rootRef = qb.collapse(root, out.nodes, 1, out.maxDepth);
+        out.pairRootRef = qb.emitPairs(root, out.pairs, 2, out.pairDepth);
+    };
+    bool built = false;
+    if (onDevice) { // the same split rule, one level per launch (query_build.hip)
+        const auto t0 = clock::now();
+        std::vector<float> lo4(size_t(n) * 4), hi4(size_t(n) * 4);
+        for (uint32_t i = 0; i < n; i++) {
+            lo4[4 * size_t(i)] = qb.lo[i].x, lo4[4 * size_t(i) + 1] = qb.lo[i].y, lo4[4 * size_t(i) + 2] = qb.lo[i].z, lo4[4 * size_t(i) + 3] = 0.0f;
+            hi4[4 * size_t(i)] = qb.hi[i].x, hi4[4 * size_t(i) + 1] = qb.hi[i].y, hi4[4 * size_t(i) + 2] = qb.hi[i].z, hi4[4 * size_t(i) + 3] = 0.0f;
+        }
+        std::vector<DeviceBuildNode> nodes;
+        uint32_t levels = 0;
+        if (device_build_query_hierarchy(lo4.data(), hi4.data(), n, qb.kLeaf, nodes, qb.idx, levels, &out.deviceKernelMs) && !nodes.empty()) {
+            qb.tree.resize(nodes.size());
+            for (size_t i = 0; i < nodes.size(); i++) {
+                qb.tree[i].lo = make3(nodes[i].lo[0], nodes[i].lo[1], nodes[i].lo[2]);
+                qb.tree[i].hi = make3(nodes[i].hi[0], nodes[i].hi[1], nodes[i].hi[2]);
+                qb.tree[i].child[0] = nodes[i].child[0], qb.tree[i].child[1] = nodes[i].child[1];
+            }
+            out.hierarchyMs = ms_since(t0);
+            const auto t1 = clock::now();
+            emit(0);
+            out.layoutMs = ms_since(t1);
+            built = out.pairDepth <= 48;
+            out.builtOnDevice = built;
+        }
+    }
+    for (int attempt = 0; attempt < 2 && !built; attempt++) {
+        const auto t0 = clock::now();
         qb.tree.clear();
-        out.nodes.clear();
         qb.sah = (attempt == 0);
         for (uint32_t i = 0; i < n; i++) qb.idx[i] = i;
         vec3 l, h;
         const uint32_t root = qb.build(0, n, l, h); // an inner node: n exceeds the largest leaf
-        out.maxDepth = 0, out.pairDepth = 1; // pairDepth counts levels of nodes as the flattener does: the root is level 1
-        out.rootRef = qb.collapse(root, out.nodes, 1, out.maxDepth);
-        out.pairs.clear();
-        out.pairRootRef = qb.emitPairs(root, out.pairs, 2, out.pairDepth);
+        out.hierarchyMs = ms_since(t0);
+        const auto t1 = clock::now();
+        emit(root);
+        out.layoutMs = ms_since(t1);
         if (out.pairDepth <= 48) break; // a degenerate heuristic tree: fall back to halving
     }
+    const auto tLayout = clock::now();
     out.triPlane.resize(n), out.triEdges.resize(n), out.cert.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t t = qb.idx[i];
@@ -523,6 +558,7 @@ void build_query_tree(const FlatScene& flat, QueryTree& out)
             }
         }
     }
+    out.layoutMs += ms_since(tLayout);
     out.usable = true;
 }
 
@@ -589,6 +625,12 @@ const uint32_t* rt_bvh_primitive_ids(const rt_bvh* b) { return b ? b->primIds.da
 
 int rt_selftest_query_tree(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, uint32_t info[8])
 {
+    return rt_selftest_query_tree_built(nodes, nNodes, prims, nPrims, nMaterials, 0, info, nullptr);
+}
+
+int rt_selftest_query_tree_built(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, uint32_t nMaterials, int onDevice,
+                                 uint32_t info[8], float times[4])
+{
     if (!nodes || !info) {
         set_error("rt_selftest_query_tree: null argument");
         return RT_ERR_INVALID;
@@ -602,7 +644,8 @@ int rt_selftest_query_tree(const void* nodes, uint32_t nNodes, const void* prims
         return rc;
     }
     QueryTree qt;
-    build_query_tree(flat, qt);
+    build_query_tree(flat, qt, onDevice != 0);
+    if (times) times[0] = qt.hierarchyMs, times[1] = qt.deviceKernelMs, times[2] = qt.layoutMs, times[3] = qt.builtOnDevice ? 1.0f : 0.0f;
     const uint32_t n = uint32_t(flat.triPlane.size());
     info[0] = qt.usable ? 1u : 0u, info[1] = n, info[2] = uint32_t(qt.pairs.size()), info[3] = qt.pairDepth;
     info[4] = uint32_t(qt.nodes.size()), info[5] = qt.maxDepth, info[6] = uint32_t(flat.pairs.size()), info[7] = flat.maxDepth;

@@ -55,8 +55,7 @@ struct Workspace {
     // Launch plan carried from one frame to the next: rt_sync notes how many rays every round of the frame held; the next
     // frame of the same description (size, depth, flags, features, region) leaves out the launches that only serve
     // larger rounds.  The plan is a hint: a round that turns out larger is still traced completely, by the group kernel alone.
-    std::vector<uint32_t> roundRays; // per path round of the frame the plan comes from
-    uint64_t planKey = 0, lastKey = 0;
+    uint64_t lastKey = 0; // what shaped the rounds of the frame last queued here
     uint32_t lastRounds = 0;
 };
 
@@ -88,6 +87,10 @@ struct rt_scene {
     std::vector<float*> texturePixels; // device copy of each material's texels (null: none)
     uint32_t treeDepth = 0;
     std::vector<RetiredFrame> retired; // what rt_sync reports for streams whose buffers were taken over
+    // launch plan: rays per path round of the last frame rt_sync looked at, and what shaped that frame's rounds; frames of the same
+    // shape on any stream size their launches by it
+    std::vector<uint32_t> roundRays;
+    uint64_t planKey = 0;
     std::vector<struct Workspace*> workspaces; // per-frame buffers, one set per stream that frames are queued on (see workspace_for)
     uint64_t useCounter = 0;
     int numCUs = 256;
@@ -1670,7 +1673,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         return RT_ERR_HIP;
     }
     QueryTree qt;
-    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt);
+    // the library's own tree: hierarchy on the device unless RT_AMD_HOST_QUERY_BUILD asks for the host builder
+    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt, getenv("RT_AMD_HOST_QUERY_BUILD") == nullptr);
     const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
@@ -1773,8 +1777,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         s->queryDepth = qt.pairDepth;
     }
     if (getenv("RT_AMD_VERBOSE"))
-        fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s\n",
-                nTris, nPairs, flat.maxDepth, nQPairs, qt.pairDepth, nQNodes, qt.maxDepth, qt.usable ? "" : " (not used)");
+        fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s; "
+                        "hierarchy built on the %s in %.2f ms (launches %.2f ms), layouts written in %.2f ms\n",
+                nTris, nPairs, flat.maxDepth, nQPairs, qt.pairDepth, nQNodes, qt.maxDepth, qt.usable ? "" : " (not used)",
+                qt.builtOnDevice ? "device" : "host", qt.hierarchyMs, qt.deviceKernelMs, qt.layoutMs);
     if (const char* e = getenv("RT_AMD_T1")) s->laneModeAbove = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BATCH_WINDOW")) s->batchWindow = (uint32_t)std::min(5, std::max(0, atoi(e)));
     if (getenv("RT_AMD_NO_BATCH")) s->batchWindow = 0;
@@ -2133,7 +2139,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
         mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
     }
-    const bool planned = !countRef && key == w.planKey && w.roundRays.size() == rounds && !scene->noPlan;
+    const bool planned = !countRef && key == scene->planKey && scene->roundRays.size() == rounds && !scene->noPlan;
     w.lastKey = key, w.lastRounds = usePath ? 0u : rounds;
 
     TraceParams T;
@@ -2351,9 +2357,9 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         // the camera kernel emits exactly one ray per active state and counts them once
         // a round counts as small when the plan's frame would have sent it to the group kernel (which is about as fast as the
         // other schedule up to half as many rays again, should this frame's round be larger)
-        const bool smallRound = planned && w.roundRays[r - 1] < laneModeAbove;
+        const bool smallRound = planned && scene->roundRays[r - 1] < laneModeAbove;
         launch_trace(w.d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? w.d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
-                     smallRound ? w.roundRays[r - 1] : 0u);
+                     smallRound ? scene->roundRays[r - 1] : 0u);
         P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);
         P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
@@ -2566,15 +2572,16 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     }
     if (w.lastWasWavefront && w.lastRounds) { // the next frame's plan
         const uint32_t n = w.lastRounds;
-        w.roundRays.assign(n, 0u);
-        RT_HIP(hipMemcpy(&w.roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
-        if (n > 1) RT_HIP(hipMemcpy(&w.roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        w.planKey = w.lastKey;
+        std::vector<uint32_t>& roundRays = scene->roundRays;
+        roundRays.assign(n, 0u);
+        RT_HIP(hipMemcpy(&roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
+        if (n > 1) RT_HIP(hipMemcpy(&roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        scene->planKey = w.lastKey;
         if (scene->verbose) { // rays traced by the path rounds (candidate batches included), round by round
             unsigned long long sum = 0;
-            for (uint32_t v : w.roundRays) sum += v;
+            for (uint32_t v : roundRays) sum += v;
             fprintf(stderr, "rt_amd: %u path rounds traced %llu rays:", n, sum);
-            for (uint32_t v : w.roundRays) fprintf(stderr, " %u", v);
+            for (uint32_t v : roundRays) fprintf(stderr, " %u", v);
             fprintf(stderr, "\n");
         }
     }

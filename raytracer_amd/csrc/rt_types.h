@@ -179,8 +179,22 @@ struct QueryTree {
     uint32_t rootRef = 0;
     uint32_t maxDepth = 0;
     bool usable = false;
+    bool builtOnDevice = false;  // the hierarchy came from device_build_query_hierarchy
+    float hierarchyMs = 0.0f;    // wall time of the hierarchy build (host: the recursive build; device: upload, launches, download)
+    float deviceKernelMs = 0.0f; // device: the launches alone
+    float layoutMs = 0.0f;       // wall time of writing the traversal layouts from the hierarchy (host)
 };
-void build_query_tree(const FlatScene& flat, QueryTree& out);
+// onDevice: try the device builder first (the host builder takes over if it cannot be used)
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice = false);
+
+// One node of a hierarchy built on the device: a child is a node index or a leaf reference (kLeafBit | count << 25 | first place in the
+// triangle order).
+struct DeviceBuildNode {
+    float lo[3], hi[3];
+    uint32_t child[2];
+};
+bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
+                                  std::vector<uint32_t>& order, uint32_t& depth, float* kernelMs);
 
 // Returns RT_OK or an error status with `err` describing it.
 int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,

@@ -360,6 +360,10 @@ __device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T
 #define RT_LEAF_BATCH 20
 #endif
 constexpr int kLeafBatch = RT_LEAF_BATCH;
+#ifndef RT_STUCK_LANES
+#define RT_STUCK_LANES 8
+#endif
+constexpr int kStuckLanes = RT_STUCK_LANES; // lanes that cannot go on without their leaf test before the wave runs it
 template <bool CULL, bool COUNT, int STACK, bool QUERY>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
@@ -373,7 +377,11 @@ __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool h
     }
     const bool parked = has && T.pend != 0;
     const bool stuck = parked && (T.cur == kTraversalDone || (T.cur & kLeafBit));
-    if (__ballot(stuck) != 0ull || __popcll(__ballot(parked)) >= kLeafBatch) {
+    const unsigned long long stuckMask = __ballot(stuck);
+    // a few stuck lanes wait for company as long as other lanes of the wave still have nodes to walk
+    const bool test = __popcll(stuckMask) >= kStuckLanes || (stuckMask != 0ull && __ballot(has && !stuck) == 0ull)
+        || __popcll(__ballot(parked)) >= kLeafBatch;
+    if (test) {
         if (parked) {
             const uint32_t first = T.pend & kRefOffsetMask, cnt = (T.pend >> kRefCountShift) & kMaxLeafCount;
             leaf_test_narrow<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc, &T.tieT);
@@ -424,6 +432,10 @@ __device__ __forceinline__ void trace_lane_clear(TraceLane& T)
 #define RT_STEPS_PER_CHECK 6
 #endif
 constexpr int kStepsPerCheck = RT_STEPS_PER_CHECK; // traversal steps between two looks at the wave's idle lanes
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 1
+#endif
+constexpr int kRefillLanes = RT_REFILL_LANES; // idle lanes a wave waits for before it starts new rays on them
 constexpr uint32_t kLaneChunk = 64;  // rays a wave takes from the shared counter at a time
 constexpr uint32_t kGroupChunk = 32; // the same for a wave whose lanes share rays
 
@@ -453,7 +465,8 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later
     for (;;) {
         const unsigned long long idle = __ballot(!has);
-        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd)) {
+        // new rays are started for several idle lanes at a time: the set-up of a ray is long and runs with only those lanes
+        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd) && (first || __popcll(idle) >= kRefillLanes)) {
             uint32_t next = 0xffffffffu;
             if (first) {
                 next = blockIdx.x * kBlock + threadIdx.x;

@@ -881,3 +881,45 @@ def test_transparent_shadows_terminate():
         compare_frames(rg, ro, f"all-transparent monkey, flags={flags}")
         assert_ray_counts(rg["stats"], ro["stats"], "all-transparent monkey")
     print("shadow queries per light sample:", ro["stats"]["shadow"] / max(1, np.count_nonzero(ro["prim"] != 0xffffffff)))
+
+
+@pytest.mark.parametrize("name", ["monkey", "teapot", "knot", "dragon"])
+def test_query_tree_built_on_the_device(name, monkeypatch):
+    """The hierarchy of the library's own tree built on the GPU (binned surface-area splits, a level per launch): the tree
+    passes the same soundness checks as the host-built one, has the host builder's size, and frames rendered with either
+    are equal bit for bit with the same traversal work to within a few per cent."""
+    import time
+    if name in ("knot", "dragon"):
+        sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.dragon_standin()
+    else:
+        sc = scenes.preset(name)
+    b = api.Bvh(sc["prims"])
+    infos, times = [], []
+    for on_device in (1, 0):
+        info, t = (C.c_uint32 * 8)(), (C.c_float * 4)()
+        rc = api.lib().rt_selftest_query_tree_built(b.nodes().ctypes.data_as(C.c_void_p), b.num_nodes, b.primitives().ctypes.data_as(C.c_void_p),
+                                                    b.num_primitives, len(sc["materials"]), on_device, info, t)
+        assert rc == api.RT_OK, api.lib().rt_last_error().decode()
+        infos.append(list(info)), times.append(list(t))
+    print(f"{name}: device build {infos[0]} hierarchy {times[0][0]:.2f} ms (launches {times[0][1]:.2f} ms), layouts {times[0][2]:.2f} ms; "
+          f"host build {infos[1]} hierarchy {times[1][0]:.2f} ms, layouts {times[1][2]:.2f} ms")
+    assert times[0][3] == 1.0 and times[1][3] == 0.0 and infos[0][0] == 1
+    assert abs(infos[0][2] - infos[1][2]) <= 0.02 * infos[1][2] and infos[0][3] <= infos[1][3] + 2  # pairs, depth
+    W, H = 480, 270
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2)
+    cg, _ = both_cameras(W, H)
+    frames, work, create_ms = [], [], []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("RT_AMD_HOST_QUERY_BUILD", "1")
+        t0 = time.perf_counter()
+        g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+        create_ms.append((time.perf_counter() - t0) * 1e3)
+        frames.append(g.render_image(cg, fg, W, H, start_depth=2))
+        work.append(g.render_image(cg, fg, W, H, start_depth=2, flags=api.RT_RENDER_COUNT_SCHEDULE)["stats"])
+    print(f"{name}: scene creation {create_ms[0]:.1f} ms with the device build, {create_ms[1]:.1f} ms with the host build")
+    assert np.array_equal(frames[0]["rgb"].view(np.uint32), frames[1]["rgb"].view(np.uint32))
+    assert np.array_equal(frames[0]["prim"], frames[1]["prim"])
+    steps = [s.queryNodeSteps + s.nodePairSteps for s in work]
+    print(f"{name}: node steps {steps}, triangle tests {[s.triangleTests for s in work]}")
+    assert abs(steps[0] - steps[1]) <= 0.05 * steps[1]

@@ -14,7 +14,16 @@ feat = api.Features(**fkw)
 cam = api.camera_from_trackball(W, H)
 frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-for _ in range(n):
-    scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), stream=stream)
+flags = api.RT_RENDER_OVERLAPPED if (len(sys.argv) > 3 and sys.argv[3] == "overlapped") else 0  # launch sizes of frames that share the GPU
+inflight = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # frames queued at once, each on a stream of its own
+if inflight > 1:
+    streams = [torch.cuda.Stream() for _ in range(inflight)]
+    frames = [torch.zeros_like(frame) for _ in range(inflight)]
+    for k in range(n):
+        scene.render_device(cam, feat, W, H, wl["start_depth"], frames[k % inflight].data_ptr(), flags=flags, stream=streams[k % inflight].cuda_stream)
+    stream = streams[0].cuda_stream
+else:
+    for _ in range(n):
+        scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), flags=flags, stream=stream)
 torch.cuda.synchronize()
 print("stats", scene.sync(stream).rays if hasattr(scene.sync(stream), "rays") else "ok")

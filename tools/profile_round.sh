@@ -1,5 +1,7 @@
 #!/bin/bash
-# usage (on the GPU box): tools/profile_round.sh <tag>   -> gpurun_out/<tag>/{bench.json,kernel_stats.csv,pmc_fetch.csv,pmc_write.csv}
+# usage (on the GPU box): tools/profile_round.sh <tag>
+#   -> gpurun_out/<tag>/{bench.json, kernel_stats.csv (one frame in flight), kernel_stats_overlapped.csv (bench defaults),
+#      bench_under_rocprof*.json, pmc_fetch.csv, pmc_write.csv}
 set -o pipefail
 tag=$1
 root=$GRAFT_REPO_ROOT
@@ -9,12 +11,18 @@ cd $root
 timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 cut -c1-200 $out/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+export GPU_MAX_HW_QUEUES=8
+# per-kernel durations of frames rendered one at a time: they add up to the frame's time alone
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 $root/bench.py --frames-in-flight 1 --steps 5 --warmup 1 --cpu-seconds 0 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 cp $out/kt/p_kernel_stats.csv $out/kernel_stats.csv
 grep -h '"metric"' $out/kt.log > $out/bench_under_rocprof.json
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o p -- python3 $root/tools/frame.py 2 > $out/pf.log 2>&1 || { tail -5 $out/pf.log; exit 1; }
+# the same with the bench's default frames in flight: kernels of different frames overlap, durations stretch
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kto -o p -- python3 $root/bench.py --steps 8 --warmup 4 --cpu-seconds 0 > $out/kto.log 2>&1 || { tail -5 $out/kto.log; exit 1; }
+cp $out/kto/p_kernel_stats.csv $out/kernel_stats_overlapped.csv
+grep -h '"metric"' $out/kto.log > $out/bench_under_rocprof_overlapped.json
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o p -- python3 $root/tools/frame.py 2 dragon_glossy_bloom overlapped > $out/pf.log 2>&1 || { tail -5 $out/pf.log; exit 1; }
 cp $out/pf/p_counter_collection.csv $out/pmc_fetch.csv
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o p -- python3 $root/tools/frame.py 2 > $out/pw.log 2>&1 || { tail -5 $out/pw.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o p -- python3 $root/tools/frame.py 2 dragon_glossy_bloom overlapped > $out/pw.log 2>&1 || { tail -5 $out/pw.log; exit 1; }
 cp $out/pw/p_counter_collection.csv $out/pmc_write.csv
-rm -rf $out/kt/p_kernel_trace.csv
+rm -rf $out/kt/p_kernel_trace.csv $out/kto/p_kernel_trace.csv
 echo done
