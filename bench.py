@@ -205,9 +205,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(F):  # set-up, not a step: every stream's frame buffers are allocated by its first frame
-        step(i, cams[i % len(cams)] if cams else None)
-    barrier()
+    # set-up, not a step: every stream's frame buffers are allocated by its first frame, and a frame whose deferred tasks
+    # overflow the default queue sizes (many glossy samples) makes the scene allocate larger ones for the frames after it
+    for attempt in range(4):
+        for i in range(F):
+            step(i, cams[i % len(cams)] if cams else None)
+        barrier()
+        again = False
+        for k in range(F):
+            try:
+                scene.sync(streams[k].cuda_stream)
+            except api.RtError as e:
+                if e.code != api.RT_ERR_AGAIN:
+                    raise
+                again = True
+        if not again:
+            break
     for i in range(args.warmup):
         step(i, cams[i % len(cams)] if cams else None)
     barrier()
@@ -270,9 +283,15 @@ def main():
         work, alg_bytes = counted(flags, True)
         counted_what = "the frame as scheduled (query tree, candidate batches, second traces)"
     except api.RtError:  # schedules without counters (a pixel per lane): the reference's rays in the caller's tree, culled
-        work, alg_bytes = counted(flags, False)
+        try:
+            work, alg_bytes = counted(flags, False)
+        except api.RtError:  # recursion trees too long for rounds: the depth-first kernel counts
+            work, alg_bytes = counted(flags | api.RT_RENDER_SERIAL, False)
         counted_what = "the reference's rays, culled walk in the caller's tree"
-    ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL, False)
+    try:
+        ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL, False)
+    except api.RtError:
+        ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL | api.RT_RENDER_SERIAL, False)
     achieved = alg_bytes * args.steps / elapsed / 1e9          # sustained over the timed region, frames in flight together
     achieved_alone = alg_bytes / (kernel_ms * 1e-3) / 1e9      # one launch sequence with the GPU to itself
     traffic, traffic_note = None, None

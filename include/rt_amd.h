@@ -26,7 +26,9 @@ typedef enum rt_status {
     RT_ERR_HIP = 2,         /* a HIP runtime call failed; message holds hipGetErrorString */
     RT_ERR_UNSUPPORTED = 3, /* reserved: no feature flag of the path is rejected at present */
     RT_ERR_NOMEM = 4,
-    RT_ERR_LIMIT = 5        /* a size beyond a documented limit (tree depth, leaf size, filter size) */
+    RT_ERR_LIMIT = 5,       /* a size beyond a documented limit (tree depth, leaf size, filter size) */
+    RT_ERR_AGAIN = 6        /* rt_sync: the frame overflowed the scene's task queues and is incomplete; the queues grow with the
+                               next rt_render of the scene - render the frame again (rt_render_image does so by itself) */
 } rt_status;
 
 /* POD mirror of Features + ExtraFeatures (src/common.h:62-115).  int32 for every bool. */

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "lib", "librt_amd.
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 
-RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT = range(6)
+RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_NOMEM, RT_ERR_LIMIT, RT_ERR_AGAIN = range(7)
 RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_TREE, RT_RENDER_OVERLAPPED = 1, 2, 4, 8, 16
 RT_PIPELINE_DEPTH_FIRST, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
 RT_RENDER_COUNT_SCHEDULE = 32

@@ -91,6 +91,9 @@ struct rt_scene {
     // shape on any stream size their launches by it
     std::vector<uint32_t> roundRays;
     uint64_t planKey = 0;
+    // task queue sizes a frame of this scene has asked for (a frame that overflowed its queues is reported by rt_sync with
+    // RT_ERR_AGAIN; the next rt_render allocates these)
+    uint64_t wantShadeTasks = 0, wantLeafTasks = 0;
     std::vector<struct Workspace*> workspaces; // per-frame buffers, one set per stream that frames are queued on (see workspace_for)
     uint64_t useCounter = 0;
     int numCUs = 256;
@@ -136,7 +139,7 @@ constexpr float kFltMin = 1.17549435e-38f;
 constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
 constexpr uint32_t kTraversalDone = 0xffffffffu;
-constexpr uint64_t kMaxQueueTasks = 1ull << 28; // per queue
+constexpr uint64_t kMaxQueueTasks = 1ull << 29; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
 constexpr uint32_t kMaxTraceLaunches = 6 * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
@@ -1962,18 +1965,19 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     uint64_t want = (uint64_t)nWork * 8u;
     if (want < (1u << 20)) want = 1u << 20;
-    if (want > kMaxQueueTasks) want = kMaxQueueTasks;
-    if (w.shadeCap < want) {
+    const uint64_t wantShade = std::min<uint64_t>(std::max(want, scene->wantShadeTasks), kMaxQueueTasks);
+    const uint64_t wantLeaf = std::min<uint64_t>(std::max(want, scene->wantLeafTasks), kMaxQueueTasks);
+    if (w.shadeCap < wantShade) {
         (void)hipFree(w.d_shadeQ);
         w.d_shadeQ = nullptr, w.shadeCap = 0;
-        RT_HIP(hipMalloc(&w.d_shadeQ, want * sizeof(ShadeTask)));
-        w.shadeCap = (uint32_t)want;
+        RT_HIP(hipMalloc(&w.d_shadeQ, wantShade * sizeof(ShadeTask)));
+        w.shadeCap = (uint32_t)wantShade;
     }
-    if (w.leafCap < want) {
+    if (w.leafCap < wantLeaf) {
         (void)hipFree(w.d_leafQ);
         w.d_leafQ = nullptr, w.leafCap = 0;
-        RT_HIP(hipMalloc(&w.d_leafQ, want * sizeof(LeafTask)));
-        w.leafCap = (uint32_t)want;
+        RT_HIP(hipMalloc(&w.d_leafQ, wantLeaf * sizeof(LeafTask)));
+        w.leafCap = (uint32_t)wantLeaf;
     }
     const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
     const bool useQuery = groupOk && cull && !countRef && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
@@ -2542,6 +2546,23 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
         rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
         return RT_ERR_LIMIT;
     }
+    if (w.lastWasWavefront) { // did every deferred task fit its queue?  The counters keep counting past the capacity.
+        uint32_t q[2];
+        RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
+        if (q[0] > w.shadeCap || q[1] > w.leafCap) {
+            // the next frame gets queues of the size this one asked for and a quarter more
+            const bool canGrow = (q[0] > w.shadeCap && w.shadeCap < kMaxQueueTasks) || (q[1] > w.leafCap && w.leafCap < kMaxQueueTasks);
+            // (leaf tasks that found no room left no shade task behind: the shade queue is sized for every leaf ray hitting)
+            const uint64_t most = std::max(q[0], q[1]);
+            scene->wantShadeTasks = std::max<uint64_t>(scene->wantShadeTasks, most + most / 4);
+            if (q[1] > w.leafCap) scene->wantLeafTasks = std::max<uint64_t>(scene->wantLeafTasks, (uint64_t)q[1] + q[1] / 4);
+            rt::set_error("task queues overflowed (%u shade tasks for %u slots, %u leaf tasks for %u slots): the frame is incomplete; %s",
+                          q[0], w.shadeCap, q[1], w.leafCap,
+                          canGrow ? "the queues grow with the next rt_render of this scene: render the frame again"
+                                  : "render with RT_RENDER_SERIAL or in smaller regions");
+            return canGrow ? RT_ERR_AGAIN : RT_ERR_LIMIT;
+        }
+    }
     if (h[S_DROPPED]) {
         rt::set_error("%llu rays or tasks found no room in the frame's buffers: the frame is incomplete; render with RT_RENDER_SERIAL "
                       "or in smaller regions", h[S_DROPPED]);
@@ -2583,16 +2604,6 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             fprintf(stderr, "rt_amd: %u path rounds traced %llu rays:", n, sum);
             for (uint32_t v : roundRays) fprintf(stderr, " %u", v);
             fprintf(stderr, "\n");
-        }
-    }
-    if (w.lastWasWavefront) { // did every deferred task fit its queue?
-        uint32_t q[2];
-        RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
-        if (q[0] > w.shadeCap || q[1] > w.leafCap) {
-            rt::set_error("task queues overflowed (%u shade tasks for %u slots, %u leaf tasks for %u slots): the frame is "
-                          "incomplete; render with RT_RENDER_SERIAL or in smaller regions",
-                          q[0], w.shadeCap, q[1], w.leafCap);
-            return RT_ERR_LIMIT;
         }
     }
     return RT_OK;
@@ -2649,7 +2660,15 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
         if (rc != RT_OK) return rc;
     }
     rc = rt_sync(scene, nullptr, stats);
-    if (rc == RT_ERR_LIMIT && !(flags & RT_RENDER_SERIAL)) // queues too small for this frame: evaluate it depth-first instead
+    for (int again = 0; rc == RT_ERR_AGAIN && again < 3; again++) { // queues too small for this frame: they have grown, render it again
+        rc = rt_render(scene, camera, features, width, height, startDepth, nullptr, flags, scene->d_rgb, primId ? scene->d_primId : nullptr,
+                       primT ? scene->d_primT : nullptr, nullptr);
+        if (rc == RT_OK && features->enableBloomEffect)
+            rc = rt_bloom(scene->d_rgb, scene->d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,
+                          features->bloomFilterIntensity, nullptr, nullptr);
+        if (rc == RT_OK) rc = rt_sync(scene, nullptr, stats);
+    }
+    if ((rc == RT_ERR_LIMIT || rc == RT_ERR_AGAIN) && !(flags & RT_RENDER_SERIAL)) // beyond the default pipeline's limits: evaluate it depth-first instead
         return rt_render_image(scene, camera, features, width, height, startDepth, flags | RT_RENDER_SERIAL, rgb, primId, primT, stats);
     if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpy(rgb, scene->d_rgb, px * 12, hipMemcpyDeviceToHost));

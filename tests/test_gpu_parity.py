@@ -337,6 +337,38 @@ def test_glossy_16_samples_renders_by_default():
     assert abs(rg["stats"].rays - (ro["stats"]["primary"] + ro["stats"]["shadow"] + ro["stats"]["secondary"])) <= 1e-4 * rg["stats"].rays
     assert rg["stats"].rays > 200 * W * H  # deep trees were walked
     assert np.abs(rg["rgb"] - rs["rgb"]).max() < 1e-5
+    assert rg["stats"].pipeline == api.RT_PIPELINE_PERSISTENT and rs["stats"].pipeline == api.RT_PIPELINE_DEPTH_FIRST
+
+
+def test_task_queues_grow_for_a_frame_that_overflows_them():
+    """A frame whose deferred tasks do not fit the scene's queues (sized for eight tasks per pixel, a million at least) is
+    reported incomplete by rt_sync with RT_ERR_AGAIN; the next rt_render of the scene allocates what the frame asked for, and
+    the frame then equals the depth-first kernel's.  rt_render_image renders again by itself."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.dragon_standin(n_u=120, n_v=24)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=16)
+    W, H = 128, 72
+    cg, _ = both_cameras(W, H, dist=2.0)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    g.render_device(cg, fg, W, H, 2, frame.data_ptr(), stream=0)
+    with pytest.raises(api.RtError) as e:
+        g.sync(0)
+    assert e.value.code == api.RT_ERR_AGAIN and "grow" in str(e.value)
+    for attempt in range(3):  # what a queue holds depends on what the queue before it could hold: sizes settle in a few frames
+        g.render_device(cg, fg, W, H, 2, frame.data_ptr(), stream=0)
+        try:
+            st = g.sync(0)
+            break
+        except api.RtError as again:
+            assert again.code == api.RT_ERR_AGAIN and attempt < 2
+    assert st.rays > 1.5e6 and st.pipeline == api.RT_PIPELINE_PERSISTENT
+    rs = g.render_image(cg, fg, W, H, start_depth=2, flags=api.RT_RENDER_SERIAL, want_ids=False)
+    assert np.abs(frame.cpu().numpy() - rs["rgb"]).max() < 1e-5 and st.rays == rs["stats"].rays
+    g2 = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    r2 = g2.render_image(cg, fg, W, H, start_depth=2, want_ids=False)  # overflows, grows, renders again
+    assert r2["stats"].pipeline == api.RT_PIPELINE_PERSISTENT
+    assert np.array_equal(r2["rgb"].view(np.uint32), frame.cpu().numpy().view(np.uint32))
 
 
 def test_frames_on_several_streams_overlap_without_mixing():
