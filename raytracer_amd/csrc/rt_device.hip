@@ -46,12 +46,14 @@ struct Workspace {
     size_t hitCap = 0;
     void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
     uint32_t* d_longList = nullptr; // indices of the rays a one-ray-per-lane launch handed over (hitCap entries)
+    uint32_t* d_longList2 = nullptr; // ... and of those its second pass handed over in turn
     uint32_t* d_fallList = nullptr; // indices of the rays a query-tree launch could not settle (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
     uint32_t dbgWaves = 0;
     std::vector<uint32_t> sliceSlots; // d_roundCounts entries that count the pixels every slice of the path stage set aside
     std::vector<uint32_t> fallSlots; // d_roundCounts entries that count the last frame's fall-back queries
+    std::vector<uint32_t> longSlots; // ... and the rays its one-ray-per-lane launches handed over
     // Launch plan carried from one frame to the next: rt_sync notes how many rays every round of the frame held; the next
     // frame of the same description (size, depth, flags, features, region) leaves out the launches that only serve
     // larger rounds.  The plan is a hint: a round that turns out larger is still traced completely, by the group kernel alone.
@@ -107,6 +109,8 @@ struct rt_scene {
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
+    uint32_t secondPassBudget = 0, secondPassBudgetOverlapped = 0; // steps of a handed-over ray's second one-ray-per-lane pass before it goes
+                                     // on to the group launch (0: no second pass; RT_AMD_QBUDGET2, RT_AMD_QBUDGET2_OVERLAPPED)
     uint32_t laneModeAboveOverlapped = 65536, queryStepBudgetOverlapped = 20; // the same two for frames that overlap with others
                                      // (RT_RENDER_OVERLAPPED; RT_AMD_T1_OVERLAPPED, RT_AMD_QBUDGET_OVERLAPPED)
     bool quadTrace = false;          // group launches in a query tree run four lanes per ray (RT_AMD_QUAD_TRACE; default: 8 or 16)
@@ -1561,7 +1565,7 @@ void free_workspace(Workspace* w)
     (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states);
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
-    (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_fallList);
+    (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_longList2), (void)hipFree(w->d_fallList);
     delete w;
 }
 
@@ -1793,6 +1797,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_T1_OVERLAPPED")) s->laneModeAboveOverlapped = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_QBUDGET2")) s->secondPassBudget = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_QBUDGET2_OVERLAPPED")) s->secondPassBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
         const int g = atoi(e);
@@ -2068,10 +2074,11 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         if (hitsWanted < w.leafCap) hitsWanted = w.leafCap;
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
         if (w.hitCap < hitsWanted) {
-            (void)hipFree(w.d_hits), (void)hipFree(w.d_longList), (void)hipFree(w.d_fallList);
-            w.d_hits = nullptr, w.d_longList = nullptr, w.d_fallList = nullptr, w.hitCap = 0;
+            (void)hipFree(w.d_hits), (void)hipFree(w.d_longList), (void)hipFree(w.d_longList2), (void)hipFree(w.d_fallList);
+            w.d_hits = nullptr, w.d_longList = nullptr, w.d_longList2 = nullptr, w.d_fallList = nullptr, w.hitCap = 0;
             RT_HIP(hipMalloc(&w.d_hits, hitsWanted * sizeof(HitRec)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_longList), hitsWanted * sizeof(uint32_t)));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_longList2), hitsWanted * sizeof(uint32_t)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_fallList), hitsWanted * sizeof(uint32_t)));
             w.hitCap = hitsWanted;
         }
@@ -2108,7 +2115,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         return RT_ERR_LIMIT;
     }
     RT_HIP(hipMemsetAsync(w.d_roundCounts, 0, countWords * sizeof(uint32_t), st));
-    w.fallSlots.clear();
+    w.fallSlots.clear(), w.longSlots.clear();
     WaveParams P;
     P.S = scene->view;
     P.cam = *camera;
@@ -2221,6 +2228,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             launch_one(1, false);
             return;
         }
+        w.longSlots.push_back(nextFetch);
         uint32_t* longCount = w.d_roundCounts + nextFetch++;
         if (useQuery) w.fallSlots.push_back(nextFetch);
         uint32_t* fallCount = w.d_roundCounts + nextFetch++;
@@ -2240,6 +2248,18 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             T.runLo = 0, T.runHi = 0xffffffffu;
             T.indirect = w.d_longList;
             T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
+            const uint32_t budget2 = useQuery ? (overlapped ? scene->secondPassBudgetOverlapped : scene->secondPassBudget) : 0u;
+            if (budget2) {
+                // Second pass, again one ray per lane: the handed-over rays are the tail of the first launch, about a tenth
+                // of its rays, and packed into full waves they cost a fifth of what they cost with several lanes per ray.
+                // Every ray is a lane's first here, so the budget is a cap: what is still unfinished after it goes on to the
+                // group launch.
+                uint32_t* longCount2 = w.d_roundCounts + nextFetch++;
+                T.stepBudget = budget2, T.longList = w.d_longList2, T.longCount = longCount2;
+                launch_one(1, useQuery);
+                T.stepBudget = 0, T.longList = w.d_longList, T.longCount = nullptr;
+                T.indirect = w.d_longList2, T.countPtr = longCount2;
+            }
             launch_one(scene->groupLanes, useQuery);
         }
         if (useQuery) { // the unsettled rays, in the reference's tree
@@ -2589,6 +2609,16 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             RT_HIP(hipMemcpy(&v, w.d_roundCounts + slot, sizeof(v), hipMemcpyDeviceToHost));
             fprintf(stderr, " %u", v);
         }
+        fprintf(stderr, "\n");
+    }
+    if (w.lastWasWavefront && scene->verbose && !w.longSlots.empty()) {
+        const uint32_t lo = w.longSlots.front(), hi = w.longSlots.back();
+        std::vector<uint32_t> c(hi - lo + 1);
+        RT_HIP(hipMemcpy(c.data(), w.d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (uint32_t slot : w.longSlots) sum += c[slot - lo];
+        fprintf(stderr, "rt_amd: rays handed over by one-ray-per-lane launches, stage by stage (%llu in all):", sum);
+        for (uint32_t slot : w.longSlots) fprintf(stderr, " %u", c[slot - lo]);
         fprintf(stderr, "\n");
     }
     if (w.lastWasWavefront && w.lastRounds) { // the next frame's plan

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
             bool unfit = false;
             if (!has) idx = next;
             if (!has && idx < total) {
+                if (P.indirect) idx = P.indirect[idx]; // from here on the ray's own index
                 const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
                 const float4 a = q[0], b = q[1];
                 has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
