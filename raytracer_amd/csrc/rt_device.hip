@@ -47,6 +47,9 @@ struct Workspace {
     void* d_shadowRays = nullptr; // shadow rays of one chunk of shade tasks
     uint32_t* d_longList = nullptr; // indices of the rays a one-ray-per-lane launch handed over (hitCap entries)
     uint32_t* d_longList2 = nullptr; // ... and of those its second pass handed over in turn
+    uint32_t* d_orderKeys = nullptr; // ray order of a big stage (hitCap entries each): keys, ray indices in key order,
+    uint32_t* d_order = nullptr;
+    uint32_t* d_orderHist = nullptr; // ... and the buckets' counters (kOrderBuckets)
     uint32_t* d_fallList = nullptr; // indices of the rays a query-tree launch could not settle (hitCap entries)
     size_t shadowCap = 0;
     bool lastWasWavefront = false;
@@ -109,6 +112,9 @@ struct rt_scene {
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
     uint32_t queryStepBudget = 16;   // the same in the query tree, whose steps take two levels at a time (RT_AMD_QBUDGET)
+    uint32_t orderRaysFrom = 0;      // the deferred stages (last-level rays, shadow rays) put their rays into a traversal order from this
+                                     // many rays on (RT_AMD_ORDER_FROM; 0 = never, the default: on the 1080p glossy frame the ordered
+                                     // launches are 8-13 % faster and the ordering costs several times that)
     uint32_t secondPassBudget = 0, secondPassBudgetOverlapped = 0; // steps of a handed-over ray's second one-ray-per-lane pass before it goes
                                      // on to the group launch (0: no second pass; RT_AMD_QBUDGET2, RT_AMD_QBUDGET2_OVERLAPPED)
     uint32_t laneModeAboveOverlapped = 65536, queryStepBudgetOverlapped = 20; // the same two for frames that overlap with others
@@ -1566,6 +1572,7 @@ void free_workspace(Workspace* w)
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
     (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_longList2), (void)hipFree(w->d_fallList);
+    (void)hipFree(w->d_orderKeys), (void)hipFree(w->d_order), (void)hipFree(w->d_orderHist);
     delete w;
 }
 
@@ -1797,6 +1804,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET")) s->queryStepBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_T1_OVERLAPPED")) s->laneModeAboveOverlapped = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_ORDER_FROM")) s->orderRaysFrom = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET2")) s->secondPassBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET2_OVERLAPPED")) s->secondPassBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
@@ -2075,10 +2083,17 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         if (shadows && hitsWanted < (size_t)chunkTasks * raysPerTask) hitsWanted = (size_t)chunkTasks * raysPerTask;
         if (w.hitCap < hitsWanted) {
             (void)hipFree(w.d_hits), (void)hipFree(w.d_longList), (void)hipFree(w.d_longList2), (void)hipFree(w.d_fallList);
+            (void)hipFree(w.d_orderKeys), (void)hipFree(w.d_order);
             w.d_hits = nullptr, w.d_longList = nullptr, w.d_longList2 = nullptr, w.d_fallList = nullptr, w.hitCap = 0;
+            w.d_orderKeys = nullptr, w.d_order = nullptr;
             RT_HIP(hipMalloc(&w.d_hits, hitsWanted * sizeof(HitRec)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_longList), hitsWanted * sizeof(uint32_t)));
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_longList2), hitsWanted * sizeof(uint32_t)));
+            if (scene->orderRaysFrom) {
+                RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_orderKeys), hitsWanted * sizeof(uint32_t)));
+                RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_order), hitsWanted * sizeof(uint32_t)));
+                if (!w.d_orderHist) RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_orderHist), kOrderBuckets * sizeof(uint32_t)));
+            }
             RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_fallList), hitsWanted * sizeof(uint32_t)));
             w.hitCap = hitsWanted;
         }
@@ -2217,11 +2232,31 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     // known on the device, so every variant is launched and those whose range does not hold the count return at once.
     // With a query tree the rays walk that tree first; the few whose result is not provably the reference's are
     // traced again in the reference's tree.
+    // order: 0 = the rays are traced as they lie; 1 / 2 = a deferred stage, whose rays are first put into a traversal order (by origin
+    // cell first / by direction first) when there are many of them
     auto launch_trace = [&](const void* rays, uint32_t stride, const uint32_t* countPtr, uint32_t sub, uint32_t maxItems, uint32_t mul, bool smallRound = false,
-                            uint32_t expected = 0) {
+                            uint32_t expected = 0, int order = 0) {
         T.rays = static_cast<const char*>(rays), T.rayStride = stride;
         T.countPtr = countPtr, T.countSub = sub, T.countMaxItems = maxItems, T.countMul = mul;
-        T.indirect = nullptr, T.stepBudget = 0, T.longList = w.d_longList, T.longCount = nullptr;
+        T.indirect = nullptr, T.indirectFrom = 0, T.stepBudget = 0, T.longList = w.d_longList, T.longCount = nullptr;
+        if (order && scene->orderRaysFrom && groupOk && !count) {
+            OrderParams O;
+            O.rays = T.rays, O.rayStride = stride;
+            O.countPtr = countPtr, O.countSub = sub, O.countMaxItems = maxItems, O.countMul = mul;
+            O.minRays = scene->orderRaysFrom;
+            for (int a = 0; a < 3; a++) {
+                const float ext = scene->view.rootHi[a] - scene->view.rootLo[a];
+                O.lo[a] = scene->view.rootLo[a], O.inv[a] = ext > 0.0f ? 1.0f / ext : 0.0f;
+            }
+            O.dirMajor = order == 2 ? 1u : 0u;
+            O.keys = w.d_orderKeys, O.hist = w.d_orderHist, O.order = w.d_order;
+            (void)hipMemsetAsync(w.d_orderHist, 0, kOrderBuckets * sizeof(uint32_t), st);
+            hipLaunchKernelGGL(order_key_kernel, dim3(taskGrid), dim3(kBlock), 0, st, O);
+            hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, st, O);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(taskGrid), dim3(kBlock), 0, st, O);
+            T.indirect = w.d_order, T.indirectFrom = scene->orderRaysFrom;
+        }
+
         T.fallList = w.d_fallList, T.fallCount = nullptr;
         T.runLo = 0, T.runHi = 0xffffffffu;
         if (!groupOk) {
@@ -2246,7 +2281,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         gridNow = groupGrid;
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
-            T.indirect = w.d_longList;
+            T.indirect = w.d_longList, T.indirectFrom = 0;
             T.countPtr = longCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
             const uint32_t budget2 = useQuery ? (overlapped ? scene->secondPassBudgetOverlapped : scene->secondPassBudget) : 0u;
             if (budget2) {
@@ -2264,7 +2299,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
         }
         if (useQuery) { // the unsettled rays, in the reference's tree
             T.runLo = 0, T.runHi = 0xffffffffu;
-            T.indirect = w.d_fallList;
+            T.indirect = w.d_fallList, T.indirectFrom = 0;
             T.countPtr = fallCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
             gridNow = std::min(groupGrid, 256u); // a handful of rays as a rule
             launch_one(scene->groupLanes, false);
@@ -2393,7 +2428,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     // what the batched loops left for later: their children's hit records and the grandchildren's rays
     if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-    launch_trace(w.d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, w.leafCap, 1);
+    launch_trace(w.d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, w.leafCap, 1, false, 0, 1);
     hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     for (uint32_t c = 0; c < nChunks; c++) {
         P.chunkBase = c * chunkTasks;
@@ -2415,7 +2450,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
                 else RT_WALK_CASE(false, true);
 #undef RT_WALK_CASE
             } else {
-                launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask);
+                launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask, false, 0, 2);
             }
             P.hits = static_cast<const HitRec*>(w.d_hits);
         } else {

@@ -999,7 +999,7 @@ __global__ __launch_bounds__(kBlock) void quad_trace_kernel(const TraceParams P)
             first = false;
             bool unfit = false;
             if (!has && next < total) {
-                idx = P.indirect ? P.indirect[next] : next;
+                idx = (P.indirect && total >= P.indirectFrom) ? P.indirect[next] : next;
                 const float4* r = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
                 const float4 a = r[0], b = r[1];
                 T.R = make_slabs(S, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z));

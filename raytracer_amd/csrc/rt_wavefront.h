@@ -223,6 +223,7 @@ struct TraceParams {
     uint32_t rayStride;       // bytes between ray records
     uint32_t runLo, runHi;    // the launch does nothing unless runLo <= number of rays < runHi (several variants share one ray list)
     const uint32_t* indirect; // ray / hit index of item i (null: i itself)
+    uint32_t indirectFrom;    // ... used only when the launch has at least this many items (an order that was made for big stages only)
     uint32_t stepBudget;      // one-ray-per-lane launches: a ray still unfinished after this many steps is handed over (0: never)
     uint32_t* longList;       // ... by appending its index here; a launch with several lanes per ray then traces it from the root
     uint32_t* longCount;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
             bool unfit = false;
             if (!has) idx = next;
             if (!has && idx < total) {
-                if (P.indirect) idx = P.indirect[idx]; // from here on the ray's own index
+                if (P.indirect && total >= P.indirectFrom) idx = P.indirect[idx]; // from here on the ray's own index
                 const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
                 const float4 a = q[0], b = q[1];
                 has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
@@ -549,6 +550,112 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
         for (uint32_t k = lane; k < nLong; k += 64u) P.longList[base + k] = s_long[(threadIdx.x >> 6) * 128 + k];
     }
     if (COUNT || __ballot(tc.overflow != 0) != 0ull) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ray order for the big one-ray-per-lane launches.  A wave walks the tree fastest when its 64 rays walk the same nodes;
+// the deferred rays of a frame (last-level glossy rays, shadow rays) are produced in the order their pixels happened to
+// finish.  Three small kernels give a stage's rays a traversal order without moving them: a key per ray (origin cell and
+// direction cell, the weight between the two chosen by the stage), a histogram of the keys, and a scatter of the ray
+// indices into key order (counting sort; the order inside a bucket is whatever the atomics make it, which no result
+// depends on: hits are stored by ray index).  The trace launches then take their rays through that index list.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kOrderKeyBits = 17;
+constexpr uint32_t kOrderBuckets = 1u << kOrderKeyBits;
+struct OrderParams {
+    const char* rays;        // RayRec at the start of each record
+    uint32_t rayStride;
+    const uint32_t* countPtr; // number of items = clamp(*countPtr - countSub, 0, countMaxItems) * countMul (as TraceParams)
+    uint32_t countSub, countMaxItems, countMul;
+    uint32_t minRays;        // fewer rays than this: nothing is ordered (the launches then take the rays as they lie)
+    float lo[3], inv[3];     // scene box: cell = (o - lo) * inv
+    uint32_t dirMajor;       // 1: rays from few origins (shadow rays: direction first); 0: origin first
+    uint32_t* keys;          // per ray
+    uint32_t* hist;          // kOrderBuckets counters, zero on entry; holds each bucket's first place after order_scan_kernel
+    uint32_t* order;         // ray indices in key order
+};
+__device__ __forceinline__ uint32_t order_total(const OrderParams& P)
+{
+    const uint32_t have = *P.countPtr;
+    const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
+    return items * P.countMul;
+}
+__device__ __forceinline__ uint32_t spread3(uint32_t v) // bits of v (up to 5) to every third place
+{
+    v = (v | (v << 8)) & 0x0000f00fu;
+    v = (v | (v << 4)) & 0x000c30c3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t spread2(uint32_t v) // bits of v (up to 8) to every second place
+{
+    v = (v | (v << 4)) & 0x0f0fu;
+    v = (v | (v << 2)) & 0x3333u;
+    v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+__device__ __forceinline__ uint32_t order_key(const OrderParams& P, const float4 a, const float4 b)
+{
+    if (a.w < 0.0f) return 0u; // no ray in this slot
+    // octahedral map of the direction to [0, 1)^2
+    const float n = fabsf(b.x) + fabsf(b.y) + fabsf(b.z);
+    float u = n > 0.0f ? b.x / n : 0.0f, v = n > 0.0f ? b.y / n : 0.0f;
+    if (b.z < 0.0f) {
+        const float uu = (1.0f - fabsf(v)) * (u >= 0.0f ? 1.0f : -1.0f), vv = (1.0f - fabsf(u)) * (v >= 0.0f ? 1.0f : -1.0f);
+        u = uu, v = vv;
+    }
+    u = fminf(fmaxf(u * 0.5f + 0.5f, 0.0f), 0.999999f), v = fminf(fmaxf(v * 0.5f + 0.5f, 0.0f), 0.999999f);
+    const float cx = fminf(fmaxf((a.x - P.lo[0]) * P.inv[0], 0.0f), 0.999999f), cy = fminf(fmaxf((a.y - P.lo[1]) * P.inv[1], 0.0f), 0.999999f),
+                cz = fminf(fmaxf((a.z - P.lo[2]) * P.inv[2], 0.0f), 0.999999f);
+    if (P.dirMajor) { // 7 + 7 bits of direction (interleaved), 1 bit of origin per axis
+        const uint32_t d = spread2((uint32_t)(u * 128.0f)) | (spread2((uint32_t)(v * 128.0f)) << 1);
+        const uint32_t o = (uint32_t)(cx * 2.0f) | ((uint32_t)(cy * 2.0f) << 1) | ((uint32_t)(cz * 2.0f) << 2);
+        return (d << 3) | o;
+    }
+    // 4 bits of origin per axis (interleaved), 3 + 2 bits of direction
+    const uint32_t o = spread3((uint32_t)(cx * 16.0f)) | (spread3((uint32_t)(cy * 16.0f)) << 1) | (spread3((uint32_t)(cz * 16.0f)) << 2);
+    return (o << 5) | ((uint32_t)(u * 8.0f) << 2) | (uint32_t)(v * 4.0f);
+}
+__global__ __launch_bounds__(kBlock) void order_key_kernel(const OrderParams P)
+{
+    const uint32_t total = order_total(P);
+    if (total < P.minRays) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)i * P.rayStride);
+        const uint32_t k = order_key(P, q[0], q[1]);
+        P.keys[i] = k;
+        atomicAdd(P.hist + k, 1u);
+    }
+}
+// one workgroup: counts -> first places (exclusive prefix sums), in place
+__global__ __launch_bounds__(1024) void order_scan_kernel(const OrderParams P)
+{
+    __shared__ uint32_t s_part[1024];
+    if (order_total(P) < P.minRays) return;
+    constexpr uint32_t kPer = kOrderBuckets / 1024;
+    const uint32_t t = threadIdx.x;
+    uint32_t local[kPer];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kPer; k++) local[k] = P.hist[t * kPer + k], sum += local[k];
+    s_part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { // inclusive scan of the per-thread sums
+        const uint32_t v = t >= off ? s_part[t - off] : 0u;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[t] - sum;
+    for (uint32_t k = 0; k < kPer; k++) {
+        P.hist[t * kPer + k] = run;
+        run += local[k];
+    }
+}
+__global__ __launch_bounds__(kBlock) void order_scatter_kernel(const OrderParams P)
+{
+    const uint32_t total = order_total(P);
+    if (total < P.minRays) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) P.order[atomicAdd(P.hist + P.keys[i], 1u)] = i;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1520,7 +1627,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             bool valid = false;
             if (!has) {
                 valid = next < total;
-                idx = (valid && P.indirect) ? P.indirect[next] : next;
+                idx = (valid && P.indirect && total >= P.indirectFrom) ? P.indirect[next] : next;
             }
             bool unfit = false;
             if (valid) {

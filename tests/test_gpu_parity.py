@@ -495,7 +495,7 @@ def test_unnested_caller_tree_is_walked_as_given():
 
 @pytest.mark.parametrize("knobs", [dict(RT_AMD_T1="1"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET="2"), dict(RT_AMD_T1="1", RT_AMD_BUDGET="4", RT_AMD_NO_QUERY_TREE="1"),
                                    dict(RT_AMD_T1="4096"), dict(RT_AMD_GROUP_LANES="16"), dict(RT_AMD_GROUP_LANES="4"), dict(RT_AMD_GROUP_LANES="32"),
-                                   dict(RT_AMD_GROUP_LANES="1"), dict(RT_AMD_NO_BATCH="1"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET="2", RT_AMD_QBUDGET2="3"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET2="12"), dict(RT_AMD_BATCH_WINDOW="2"), dict(RT_AMD_BATCH_WINDOW="3"), dict(RT_AMD_QLEAF="2"), dict(RT_AMD_TRACE_BLOCKS="1", RT_AMD_T1="1"),
+                                   dict(RT_AMD_GROUP_LANES="1"), dict(RT_AMD_NO_BATCH="1"), dict(RT_AMD_ORDER_FROM="1000", RT_AMD_T1="1"), dict(RT_AMD_ORDER_FROM="100"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET="2", RT_AMD_QBUDGET2="3"), dict(RT_AMD_T1="1", RT_AMD_QBUDGET2="12"), dict(RT_AMD_BATCH_WINDOW="2"), dict(RT_AMD_BATCH_WINDOW="3"), dict(RT_AMD_QLEAF="2"), dict(RT_AMD_TRACE_BLOCKS="1", RT_AMD_T1="1"),
                                    # the path stage as persistent launches instead of rounds: a group of lanes, one lane, four lanes per pixel
                                    dict(RT_AMD_PATH_MODE="1"), dict(RT_AMD_PATH_MODE="1", RT_AMD_GROUP_LANES="16"), dict(RT_AMD_PATH_MODE="2"),
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_NO_QUERY_TREE="1"), dict(RT_AMD_PATH_MODE="2", RT_AMD_SCATTER="1"),
