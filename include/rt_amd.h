@@ -186,6 +186,20 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
               int startDepth, const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId,
               float* d_primT, void* stream);
 
+/* The loop that renders one frame per camera (src/main.cpp:515-526: for every camera of the configuration, renderImage
+ * into a Screen and write it out) as ONE launch sequence: nFrames frames of the same scene, features, size and region,
+ * frame f seen from cameras[f].  The frames are independent; rendering them together lets every stage of the pipeline
+ * trace the rays of all frames in the same launches (a stage of one 1080p frame is too small to fill 256 CUs, and the
+ * dependent stages of a frame are many).  d_rgb: DEVICE, nFrames * W*H*3 floats, frame f at offset f * W*H*3, each in
+ * Screen order; d_primId / d_primT likewise (optional, nFrames * W*H).  Every frame is bit for bit what rt_render
+ * writes for its camera.  rt_sync reports the counters of all nFrames frames together.  At most RT_MAX_FRAMES frames
+ * and nFrames * height <= 65535; frames that need RT_RENDER_SERIAL or the pixel-per-lane schedule are rendered one
+ * after the other on the stream. */
+#define RT_MAX_FRAMES 16
+int rt_render_frames(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width,
+                     int height, int startDepth, const rt_region* region, uint32_t flags, float* d_rgb,
+                     uint32_t* d_primId, float* d_primT, void* stream);
+
 /* postprocessImageWithBloom (src/extra.cpp:330-416) in place on a DEVICE Screen-order image.
  * d_scratch: DEVICE buffer of at least rt_bloom_scratch_bytes(W,H) bytes.  With a region, only that
  * region's rows are written (all rows of the input must hold the pre-bloom frame). */

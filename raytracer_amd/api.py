@@ -19,6 +19,7 @@ RT_RENDER_COUNT_WORK, RT_RENDER_NO_CULL, RT_RENDER_SERIAL, RT_RENDER_REFERENCE_T
 RT_PIPELINE_DEPTH_FIRST, RT_PIPELINE_ROUNDS, RT_PIPELINE_PERSISTENT = 0, 1, 2
 RT_RENDER_COUNT_SCHEDULE = 32
 RT_BLOOM_STATIC_MAX_PIXELS = 1 << 21
+RT_MAX_FRAMES = 16
 NO_HIT = 0xFFFFFFFF
 FLT_MAX = float(np.finfo(np.float32).max)
 
@@ -111,6 +112,8 @@ def lib():
     L.rt_scene_set_texture.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_int]
     L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.POINTER(Region), C.c_uint32,
                             vp, vp, vp, vp]
+    L.rt_render_frames.argtypes = [vp, C.POINTER(Camera), C.c_int, C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.POINTER(Region),
+                                   C.c_uint32, vp, vp, vp, vp]
     L.rt_bloom_scratch_bytes.restype = C.c_size_t
     L.rt_bloom_scratch_bytes.argtypes = [C.c_int, C.c_int]
     L.rt_bloom.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_float, C.c_float, C.POINTER(Region), vp]
@@ -251,6 +254,12 @@ class Scene:
         """rt_render on caller-owned device memory (integers = device addresses). Asynchronous."""
         check(lib().rt_render(self.h, C.byref(cam), C.byref(features), W, H, start_depth, C.byref(region) if region else None, flags,
                               d_rgb, d_prim, d_t, stream))
+
+    def render_frames_device(self, cams, features, W, H, start_depth, d_rgb, d_prim=None, d_t=None, region=None, flags=0, stream=None):
+        """rt_render_frames: one frame per camera in one launch sequence; frame f at d_rgb + f * W*H*3 floats. Asynchronous."""
+        arr = (Camera * len(cams))(*cams)
+        check(lib().rt_render_frames(self.h, arr, len(cams), C.byref(features), W, H, start_depth, C.byref(region) if region else None,
+                                     flags, d_rgb, d_prim, d_t, stream))
 
     def sync(self, stream=None) -> Stats:
         st = Stats()

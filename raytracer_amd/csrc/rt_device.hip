@@ -28,6 +28,7 @@ struct Workspace {
     uint64_t lastUse = 0;
     unsigned long long* d_stats = nullptr; // kStatCopies copies of the S_COUNT counters
     uint32_t* d_work = nullptr;            // work-fetch counter
+    rt_camera* d_cams = nullptr;           // cameras of a launch sequence that renders several frames (RT_MAX_FRAMES entries)
     // wavefront pipeline buffers (sized on demand by rt_render)
     long long* d_accum = nullptr;
     uint32_t* d_nonfinite = nullptr;
@@ -1567,7 +1568,7 @@ size_t padded(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 void free_workspace(Workspace* w)
 {
     if (!w) return;
-    (void)hipFree(w->d_stats), (void)hipFree(w->d_work), (void)hipFree(w->d_accum), (void)hipFree(w->d_nonfinite);
+    (void)hipFree(w->d_stats), (void)hipFree(w->d_work), (void)hipFree(w->d_cams), (void)hipFree(w->d_accum), (void)hipFree(w->d_nonfinite);
     (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states);
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
@@ -1872,19 +1873,32 @@ void rt_scene_destroy(rt_scene* s)
     delete s;
 }
 
-int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height, int startDepth,
-              const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId, float* d_primT, void* stream)
+// rt_render_frames for frames that can share one launch sequence.  kNotPooled (nothing has been launched then): this
+// description of a frame is rendered by a schedule that takes one frame at a time.  keepStats: the ray counters go on from
+// the frame queued before on this stream.
+static constexpr int kNotPooled = -1000;
+static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const int nFrames, const rt_features* features, int width, int height,
+                              int startDepth, const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId, float* d_primT, void* stream,
+                              const bool keepStats)
 {
     if (!scene || !camera || !features || !d_rgb || width <= 0 || height <= 0) {
         rt::set_error("rt_render: null argument or empty frame");
+        return RT_ERR_INVALID;
+    }
+    if (nFrames < 1 || nFrames > RT_MAX_FRAMES) {
+        rt::set_error("rt_render_frames: %d frames outside [1,%d]", nFrames, (int)RT_MAX_FRAMES);
         return RT_ERR_INVALID;
     }
     if (startDepth < 0 || startDepth > RT_MAX_RAY_DEPTH) {
         rt::set_error("rt_render: startDepth %d outside [0,%d]", startDepth, (int)RT_MAX_RAY_DEPTH);
         return RT_ERR_INVALID;
     }
-    if ((long long)width * height > (1ll << 30)) {
-        rt::set_error("rt_render: frame of %dx%d pixels exceeds the 2^30 pixel limit", width, height);
+    if ((long long)width * height * nFrames > (1ll << 30)) {
+        rt::set_error("rt_render: %d frame(s) of %dx%d pixels exceed the 2^30 pixel limit", nFrames, width, height);
+        return RT_ERR_LIMIT;
+    }
+    if (nFrames > 1 && (long long)height * nFrames > 65535) { // a pixel's packed position keeps frame * height + y in 16 bits
+        rt::set_error("rt_render_frames: %d frames of %d rows exceed 65535 rows per launch sequence", nFrames, height);
         return RT_ERR_LIMIT;
     }
     int rc = check_features(features);
@@ -1909,8 +1923,8 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     const int stripes = (tileRows + stripeTileRows - 1) / stripeTileRows;
     const int myStripes = (stripes > reg.rank) ? (stripes - reg.rank + reg.world - 1) / reg.world : 0;
     const int myTileRows = myStripes * stripeTileRows;
-    const uint32_t nWork = (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
-    RT_HIP(hipMemsetAsync(w.d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
+    const uint32_t nWork = (uint32_t)nFrames * (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
+    if (!keepStats) RT_HIP(hipMemsetAsync(w.d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
     RT_HIP(hipMemsetAsync(w.d_work, 0, 256, st));
     w.lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
@@ -1948,6 +1962,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     // the depth-first kernel: on request, and for transparent frames whose recursion tree is too long for rounds
     if ((flags & RT_RENDER_SERIAL) || transparentChain > kMaxRounds - 1) {
+        if (nFrames > 1) return kNotPooled;
         RenderParams P;
         P.S = scene->view;
         P.cam = *camera;
@@ -1967,7 +1982,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
 
     // ---- wavefront pipeline ----
-    const size_t px = (size_t)width * height;
+    const size_t px = (size_t)width * height * (size_t)nFrames;
     if (px > w.accumPixels) {
         (void)hipFree(w.d_accum), (void)hipFree(w.d_nonfinite);
         w.d_accum = nullptr, w.d_nonfinite = nullptr, w.accumPixels = 0;
@@ -2016,6 +2031,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     }
     const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count && !features->enableTransparency;
     const bool usePath = usePathGroup || usePathLane;
+    if (usePath && nFrames > 1) return kNotPooled; // the persistent schedules take one frame at a time
     // (rounds only) a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
     uint32_t batchRays = 0, batchWindow = 0;
     if (!usePath) {
@@ -2133,11 +2149,19 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     w.fallSlots.clear(), w.longSlots.clear();
     WaveParams P;
     P.S = scene->view;
-    P.cam = *camera;
     P.F = *features;
     P.W = width, P.H = height, P.startDepth = startDepth;
     P.tilesX = tilesX, P.myTileRows = myTileRows, P.stripeTileRows = stripeTileRows;
     P.rank = reg.rank, P.world = reg.world;
+    P.frames = nFrames;
+    { // the cameras reach the kernels through device memory: a lane picks its frame's
+        if (!w.d_cams) RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_cams), RT_MAX_FRAMES * sizeof(rt_camera)));
+        CameraPack pack;
+        for (int f = 0; f < nFrames; f++) pack.c[f] = camera[f];
+        for (int f = nFrames; f < RT_MAX_FRAMES; f++) pack.c[f] = camera[0];
+        hipLaunchKernelGGL(store_cameras_kernel, dim3(1), dim3(64), 0, st, pack, w.d_cams);
+        P.cams = w.d_cams;
+    }
     P.nWork = nWork;
     P.rgb = d_rgb, P.primId = d_primId, P.primT = d_primT;
     P.stats = w.d_stats, P.work = w.d_work;
@@ -2162,7 +2186,7 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
             const unsigned char* b = static_cast<const unsigned char*>(p);
             for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 1099511628211ull;
         };
-        const int32_t dims[5] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays };
+        const int32_t dims[6] = { width, height, startDepth, (int32_t)flags, (int32_t)batchRays, nFrames };
         mix(dims, sizeof(dims)), mix(features, sizeof(*features)), mix(&reg, sizeof(reg));
     }
     const bool planned = !countRef && key == scene->planKey && scene->roundRays.size() == rounds && !scene->noPlan;
@@ -2462,6 +2486,27 @@ int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* featu
     RT_HIP(hipGetLastError());
     w.lastWasWavefront = true;
     return RT_OK;
+}
+
+int rt_render_frames(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width, int height, int startDepth,
+                     const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId, float* d_primT, void* stream)
+{
+    int rc = render_frames_impl(scene, cameras, nFrames, features, width, height, startDepth, region, flags, d_rgb, d_primId, d_primT, stream, false);
+    if (rc != kNotPooled) return rc;
+    // schedules that take one frame at a time (depth-first, a pixel per lane): the frames one after the other on the stream
+    const size_t px = (size_t)width * height;
+    for (int f = 0; f < nFrames; f++) {
+        rc = render_frames_impl(scene, cameras + f, 1, features, width, height, startDepth, region, flags, d_rgb + 3 * px * f,
+                                d_primId ? d_primId + px * f : nullptr, d_primT ? d_primT + px * f : nullptr, stream, f > 0);
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height, int startDepth,
+              const rt_region* region, uint32_t flags, float* d_rgb, uint32_t* d_primId, float* d_primT, void* stream)
+{
+    return render_frames_impl(scene, camera, 1, features, width, height, startDepth, region, flags, d_rgb, d_primId, d_primT, stream, false);
 }
 
 size_t rt_bloom_scratch_bytes(int width, int height)

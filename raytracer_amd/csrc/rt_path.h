@@ -89,7 +89,7 @@ __device__ __forceinline__ void pixel_ray(const WaveParams& P, const uint32_t px
         ndcX = ((float)px + 0.5f) / (float)P.W * 2.f - 1.f;
         ndcY = ((float)py + 0.5f) / (float)P.H * 2.f - 1.f;
     }
-    camera_ray(P.cam, ndcX, ndcY, o, d);
+    camera_ray(P.cams[0], ndcX, ndcY, o, d);
 }
 
 // Advances the pixel of every group with `pending` from "its ray (ro, rd) ended at tt on ttri" to its next ray

@@ -60,10 +60,14 @@ constexpr float kFixLimit = 4.0e6f;           // |value| beyond this is recorded
 
 struct WaveParams {
     SceneView S;
-    rt_camera cam;
     rt_features F;
     int W, H, startDepth;
     int tilesX, myTileRows, stripeTileRows, rank, world;
+    // Several frames in one launch sequence (rt_render_frames): the frames lie one after the other in rgb / primId / primT and
+    // in the pixel sums, frame f takes work items [f, f + 1) * myTileRows * tilesX * 64 and the camera cams[f]; a pixel's
+    // packed position holds f * H + y in its row half.
+    int frames;
+    const rt_camera* cams; // device memory, `frames` entries (store_cameras_kernel)
     uint32_t nWork;
     float* rgb;
     uint32_t* primId;
@@ -719,7 +723,9 @@ __device__ __forceinline__ uint32_t pixel_ray_count(const rt_features& F)
 __device__ __forceinline__ void make_pixel_ray(const WaveParams& P, PathLane& L, const uint32_t k, const uint32_t nPixelRays)
 {
     const rt_features& F = P.F;
-    const uint32_t px = L.pxy & 0xffffu, py = L.pxy >> 16;
+    const uint32_t px = L.pxy & 0xffffu;
+    uint32_t py = L.pxy >> 16, frame = 0;
+    if (P.frames > 1) frame = py / (uint32_t)P.H, py -= frame * (uint32_t)P.H;
     float ndcX, ndcY;
     if (F.numPixelSamples > 1) { // offsets are drawn for every pixel ray before any is traced
         uint32_t s2 = L.seed;
@@ -737,7 +743,7 @@ __device__ __forceinline__ void make_pixel_ray(const WaveParams& P, PathLane& L,
         ndcX = ((float)px + 0.5f) / (float)P.W * 2.f - 1.f;
         ndcY = ((float)py + 0.5f) / (float)P.H * 2.f - 1.f;
     }
-    camera_ray(P.cam, ndcX, ndcY, L.to, L.td);
+    camera_ray(P.cams[frame], ndcX, ndcY, L.to, L.td);
     L.curW = splat(1.0f / static_cast<float>(nPixelRays)); // renderRays: L / rays.size()
     L.depth = P.startDepth;
     L.loopDepth = -1;
@@ -1205,6 +1211,16 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
     } while (__syncthreads_or(L.state > PS_TRACE));
 }
 
+// The cameras of a launch sequence that renders several frames, from the kernel's arguments into device memory (a lane
+// reads the camera of its pixel's frame; an argument array indexed per lane would be copied to scratch memory).
+struct CameraPack {
+    rt_camera c[RT_MAX_FRAMES];
+};
+__global__ __launch_bounds__(64) void store_cameras_kernel(const CameraPack pack, rt_camera* out)
+{
+    if (threadIdx.x < RT_MAX_FRAMES) out[threadIdx.x] = pack.c[threadIdx.x];
+}
+
 // Round 0: camera rays.  Most pixels of a frame look past the scene: only a pixel whose ray enters the root
 // box (or that has further pixel samples to take) gets a recursion state and a ray to trace.
 __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
@@ -1220,15 +1236,18 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
     auto pixel_setup = [&](const uint32_t w, PathLane& L) -> bool {
         if (w >= P.nWork) return false;
         const uint32_t tile = w >> 6, l = w & 63;
-        const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
+        uint32_t m = tile / P.tilesX, frame = 0;
+        const uint32_t tx = tile - m * P.tilesX;
+        if (P.frames > 1) frame = m / (uint32_t)P.myTileRows, m -= frame * (uint32_t)P.myTileRows;
         const uint32_t blk = m / P.stripeTileRows, r = m - blk * P.stripeTileRows;
         const uint32_t ty = (blk * P.world + P.rank) * P.stripeTileRows + r;
         const uint32_t px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
         if (!(px < (uint32_t)P.W && py < (uint32_t)P.H)) return false;
-        L.pixel = (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px; // Screen::indexAt (src/screen.cpp:119-122)
+        // Screen::indexAt (src/screen.cpp:119-122), in the frame's own image
+        L.pixel = frame * (uint32_t)(P.W * P.H) + (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px;
         L.seed = static_cast<uint32_t>(P.H * (int)px + (int)py);      // src/render.cpp:38
         L.smp = L.seed;
-        L.pxy = px | (py << 16);
+        L.pxy = px | ((frame * (uint32_t)P.H + py) << 16);
         for (uint32_t k = 0; k < (F.numPixelSamples > 1 ? 2 * nPixelRays : 0u); k++) (void)sampler_next(L.smp);
         make_pixel_ray(P, L, 0, nPixelRays);
         return true;
@@ -1296,7 +1315,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
 template <bool TRANSP>
-__global__ __launch_bounds__(kBlock) void path_logic_kernel(const WaveParams P)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void path_logic_kernel(const WaveParams P)
 {
     __shared__ uint32_t s_n[12], s_base[3];
     const int lane = threadIdx.x & 63;
@@ -1998,12 +2017,14 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(const WaveParams P)
 {
     for (uint32_t w = blockIdx.x * kBlock + threadIdx.x; w < P.nWork; w += gridDim.x * kBlock) {
         const uint32_t tile = w >> 6, l = w & 63;
-        const uint32_t m = tile / P.tilesX, tx = tile - m * P.tilesX;
+        uint32_t m = tile / P.tilesX, frame = 0;
+        const uint32_t tx = tile - m * P.tilesX;
+        if (P.frames > 1) frame = m / (uint32_t)P.myTileRows, m -= frame * (uint32_t)P.myTileRows;
         const uint32_t blk = m / P.stripeTileRows, r = m - blk * P.stripeTileRows;
         const uint32_t ty = (blk * P.world + P.rank) * P.stripeTileRows + r;
         const uint32_t px = tx * 8 + (l & 7), py = ty * 8 + (l >> 3);
         if (px >= (uint32_t)P.W || py >= (uint32_t)P.H) continue;
-        const uint32_t pixel = (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px;
+        const uint32_t pixel = frame * (uint32_t)(P.W * P.H) + (uint32_t)(P.H - 1 - (int)py) * (uint32_t)P.W + px;
         long long* a = P.accum + 3 * (size_t)pixel;
         const uint32_t nf = P.nonfinite[pixel];
         float out[3];

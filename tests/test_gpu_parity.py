@@ -394,6 +394,60 @@ def test_frames_on_several_streams_overlap_without_mixing():
     assert len({w["stats"].rays for w in want}) > 1  # the frames do differ
 
 
+def test_frames_rendered_together_equal_frames_rendered_alone():
+    """rt_render_frames (the reference's loop over cameras, src/main.cpp:515-526, as one launch sequence whose stages trace the
+    rays of every frame together) writes, for each camera, the frame, primary ids and distances of rt_render bit for bit, and
+    counts the rays of all frames; also for one rank's stripes, with several rays per pixel (the camera of a pixel's frame
+    is looked up again for every pixel ray), with the oracle as the judge of one of the frames, and for frames that the
+    depth-first kernel or the pixel-per-lane schedule must render one at a time."""
+    torch = pytest.importorskip("torch")
+    g, o, _ = scene_pair("knot")
+    W, H = 320, 184
+    pairs = [both_cameras(W, H, dist=2.0 + 0.3 * k, rot_deg=(20.0 - 5.0 * k, 20.0 + 70.0 * k, 0.0)) for k in range(5)]
+    cams = [p[0] for p in pairs]
+    s0 = torch.cuda.current_stream().cuda_stream
+    cases = [("glossy x3", dict(enableGlossyReflection=1, numGlossySamples=3), 2, None, 0),
+             ("glossy x3, stripes of rank 1 of 3", dict(enableGlossyReflection=1, numGlossySamples=3), 2, api.Region(8, 1, 3), 0),
+             ("mirror, 4 jittered pixel rays", dict(numPixelSamples=4, enableJitteredSampling=1), 3, None, 0),
+             ("glossy x16 (pixel per lane, frame by frame)", dict(enableGlossyReflection=1, numGlossySamples=16), 4, None, 0),
+             ("depth-first kernel, frame by frame", dict(enableGlossyReflection=1, numGlossySamples=2), 3, None, api.RT_RENDER_SERIAL)]
+    for what, kw, depth, region, flags in cases:
+        fg, fo = both_features(**kw)
+        n = len(cams)
+        rgb = torch.full((n, H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+        ids = torch.full((n, H, W), 7, dtype=torch.int32, device="cuda")
+        ts = torch.full((n, H, W), -1.0, dtype=torch.float32, device="cuda")
+        one = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+        one_id = torch.full((H, W), 7, dtype=torch.int32, device="cuda")
+        one_t = torch.full((H, W), -1.0, dtype=torch.float32, device="cuda")
+
+        def rendered(queue):  # a frame that overflows the scene's task queues makes them grow: render it again (rt_sync: RT_ERR_AGAIN)
+            for attempt in range(4):
+                queue()
+                try:
+                    return g.sync(s0)
+                except api.RtError as e:
+                    assert e.code == api.RT_ERR_AGAIN and attempt < 3
+        for rep in range(2):  # the second pass runs with the launch plan of the first
+            together = rendered(lambda: g.render_frames_device(cams, fg, W, H, depth, rgb.data_ptr(), ids.data_ptr(), ts.data_ptr(), region=region,
+                                                               flags=flags, stream=s0))
+            rays = 0
+            for k, c in enumerate(cams):
+                one.fill_(-1.0), one_id.fill_(7), one_t.fill_(-1.0)
+                rays += rendered(lambda: g.render_device(c, fg, W, H, depth, one.data_ptr(), one_id.data_ptr(), one_t.data_ptr(), region=region,
+                                                         flags=flags, stream=s0)).rays
+                assert torch.equal(rgb[k].view(torch.int32), one.view(torch.int32)), f"{what}: frame {k}, pass {rep}"
+                assert torch.equal(ids[k], one_id) and torch.equal(ts[k].view(torch.int32), one_t.view(torch.int32)), f"{what}: ids of frame {k}"
+            assert together.rays == rays, what
+        if region is None and flags == 0 and depth < 4:
+            k = 3
+            ro = o.render(pairs[k][1], fo, W, H, start_depth=depth)
+            got = dict(rgb=rgb[k].cpu().numpy(), prim=ids[k].cpu().numpy().view(np.uint32), t=ts[k].cpu().numpy())
+            compare_frames(got, ro, f"{what}: frame {k} of {n} rendered together")
+    with pytest.raises(api.RtError):
+        g.render_frames_device(cams * 4, both_features()[0], W, H, 2, rgb.data_ptr(), stream=s0)  # 20 frames > RT_MAX_FRAMES
+
+
 def test_wavefront_matches_serial_and_is_reproducible():
     """The default pipeline (deferred shadow / last-level rays, fixed-point pixel sums) against the depth-first
     kernel that sums in the reference's nested order; and two runs of it bit for bit."""

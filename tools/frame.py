@@ -6,7 +6,7 @@ import bench
 from raytracer_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 wl = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "dragon_glossy_bloom"]
-W, H = 1920, 1080
+W, H = wl.get("width", 1920), wl.get("height", 1080)
 sc = bench.build_scene_arrays(wl["scene"])
 scene = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
 fkw = dict(bench.FEATURE_BASE); fkw.update(wl["feat"])

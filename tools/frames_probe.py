@@ -1,0 +1,60 @@
+"""Throughput of the headline frame rendered K frames per launch sequence (rt_render_frames) on S streams.
+
+usage: python tools/frames_probe.py K:S[:flags] ...   e.g. 1:4 4:1 4:2 8:2   (flags: o = RT_RENDER_OVERLAPPED)
+A step is one frame: render + bloom + copy to pinned host memory, as in bench.py.
+"""
+import os, sys, time
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_PROBE_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from raytracer_amd import api
+
+wl = bench.WORKLOADS[os.environ.get("RT_PROBE_WORKLOAD", "dragon_glossy_bloom")]
+W, H = wl.get("width", 1920), wl.get("height", 1080)
+world = int(os.environ.get("RT_PROBE_WORLD", "1"))
+sc = bench.build_scene_arrays(wl["scene"], None)
+fkw = dict(bench.FEATURE_BASE); fkw.update(wl["feat"])
+feat = api.Features(**fkw)
+cam = api.camera_from_trackball(W, H)
+dev = torch.device("cuda", 0)
+reg = api.Region(8, 0, world)
+for spec in sys.argv[1:]:
+    parts = spec.split(":")
+    K, S = int(parts[0]), int(parts[1])
+    fl = api.RT_RENDER_OVERLAPPED if (len(parts) > 2 and "o" in parts[2]) else 0
+    scene = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])  # a scene keeps a buffer set per stream: start afresh
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    frames = [torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev) for _ in range(S)]
+    scratch = [torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev) for _ in range(S)]
+    host = [torch.empty((K, H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(S)]
+
+    def batch(i):
+        k = i % S
+        st = streams[k]
+        with torch.cuda.stream(st):
+            scene.render_frames_device([cam] * K, feat, W, H, wl["start_depth"], frames[k].data_ptr(), region=reg, flags=fl, stream=st.cuda_stream)
+            for f in range(K if not os.environ.get("RT_PROBE_NO_BLOOM") else 0):
+                api.bloom_device(frames[k][f].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
+                                 feat.bloomFilterIntensity, stream=st.cuda_stream)
+            if not os.environ.get("RT_PROBE_NO_COPY"):
+                host[k].copy_(frames[k], non_blocking=True)
+    for rep in range(3):
+        for i in range(S):
+            batch(i)
+        torch.cuda.synchronize()
+        for k in range(S):
+            try:
+                stats = scene.sync(streams[k].cuda_stream)
+            except api.RtError as e:
+                print("  (set-up pass %d: %s)" % (rep, e))
+    rays = (stats.primaryRays + stats.shadowRays + stats.secondaryRays) / K
+    n = max(2 * S, 24 // K)
+    t0 = time.perf_counter()
+    for i in range(n):
+        batch(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (n * K)
+    print("%2d frames per sequence on %d stream(s)%s, world %d: %.3f ms per frame, %.0f Mrays/s per GPU" % (K, S, " (overlapped sizes)" if fl else "", world, dt * 1e3, rays / dt / 1e6), flush=True)
+    del streams, frames, scratch, host, scene
+    torch.cuda.empty_cache()
