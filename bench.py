@@ -4,14 +4,17 @@
   python bench.py --gpus N --steps K --warmup W            (N = 1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one frame, as the reference's renderImage delivers it: rt_render (+ all-gather of the row stripes when
-N > 1) + rt_bloom + the copy of the finished frame into a pinned host buffer.  The scene is resident in HBM.  Frames are
-independent, so up to `--frames-in-flight` of them are queued on streams of their own and overlap on the GPU (the path
-stage of one frame is a chain of short dependent launches that leaves most of the chip idle); `ms_per_step` is the
-elapsed time of the K steps divided by K, `ms_per_frame_alone` what one frame takes with nothing else queued.  With
-N > 1 the frame is cut into interleaved 8-row stripes, stripe s belongs to rank s % N, and every rank ends each step
-holding the full post-bloom frame.  Rank 0 prints one JSON line.  `value` counts every closest-hit query that
-contributes to the image (primary + shadow + reflection rays) over all ranks, divided by the slowest rank's time.
+A step = one frame, as the reference's renderImage delivers it: render (+ exchange of the row stripes when N > 1) +
+rt_bloom + the copy of the finished frame into a pinned host buffer.  The scene is resident in HBM.  Frames are
+independent (the reference renders one per camera, src/main.cpp:515-526), and the path stage of ONE frame is a chain of
+short dependent launches that leaves most of the chip idle, so the steps are rendered `--frames-per-sequence` at a time by
+rt_render_frames - one launch sequence whose stages trace the rays of all its frames together - and up to
+`--frames-in-flight` such sequences are queued on streams of their own and overlap on the GPU.  `ms_per_step` is the
+elapsed time of the K steps divided by K, `ms_per_frame_alone` what one frame takes with nothing else queued (rt_render).
+With N > 1 every frame is cut into interleaved 8-row stripes, stripe s belongs to rank s % N; the stripes of a sequence
+are exchanged with one all-to-all that leaves frame f whole on rank f % N, which blooms it and copies it to the host:
+every frame of the job ends in host memory once.  Rank 0 prints one JSON line.  `value` counts every closest-hit query
+that contributes to the image (primary + shadow + reflection rays) over all ranks, divided by the slowest rank's time.
 """
 import argparse
 import json
@@ -118,7 +121,9 @@ def main():
     ap.add_argument("--obj", default=None, help="Wavefront OBJ to use where a workload names the dragon")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-cull", action="store_true", help="traverse exactly as the reference (no distance culling)")
-    ap.add_argument("--frames-in-flight", type=int, default=4, help="frames queued at once, each on its own stream (1..8)")
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="launch sequences queued at once, each on its own stream (1..8)")
+    ap.add_argument("--frames-per-sequence", type=int, default=8,
+                    help="frames rendered by one launch sequence (rt_render_frames; 1..16); fewer when the steps do not fill the streams")
     ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0: leave the environment's value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
@@ -168,48 +173,62 @@ def main():
     flags = api.RT_RENDER_NO_CULL if args.no_cull else 0
 
     F = max(1, min(8, args.frames_in_flight))
+    K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence, -(-max(args.steps, 1) // F)))  # frames per launch sequence
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
-    frames = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    frames = [torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
     scratch = [torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev) for _ in range(F)]
-    host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(F)]  # what the caller's Screen::pixels() aliases
+    host = [torch.empty((K, H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(F)]  # what the caller's Screen::pixels() alias
     from raytracer_amd.stripes import StripePlan
     plans = [StripePlan(H, W, rank, world, stripe_rows=8, device=dev if args.backend == "nccl" else "cpu") for _ in range(F)]
+    last_count = [0] * F
 
-    def step(i, c=None, ev=None, fl=None):
-        """Frame i: queued on stream i % F; nothing waits on the host."""
+    def sequences(n):
+        """n steps as launch sequences of up to K frames: (first frame, frames)."""
+        return [(a, min(K, n - a)) for a in range(0, n, K)]
+
+    def run(i, first, count, ev=None, fl=None):
+        """Launch sequence i = frames [first, first + count): queued on stream i % F; nothing waits on the host."""
         k = i % F
         st = streams[k]
+        seq_cams = [cams[(first + f) % len(cams)] for f in range(count)] if cams else [cam] * count
+        last_count[k] = count
         with torch.cuda.stream(st):
             if ev:
                 ev[0].record(st)
-            scene.render_device(c or cam, feat, W, H, wl["start_depth"], frames[k].data_ptr(), region=region,
-                                flags=flags_timed if fl is None else fl, stream=st.cuda_stream)
+            scene.render_frames_device(seq_cams, feat, W, H, wl["start_depth"], frames[k].data_ptr(), region=region,
+                                       flags=flags_timed if fl is None else fl, stream=st.cuda_stream)
             if ev:
                 ev[1].record(st)
+            mine = range(count)  # the frames this rank completes
             if world > 1:
                 if args.backend == "nccl":
-                    plans[k].gather(frames[k], dist)
-                else:  # stripes through host memory: this rank's stripes down, everyone's up
+                    mine = plans[k].assemble(frames[k][:count], dist)
+                else:  # stripes through host memory: this rank's stripes down, the frames it is the root of up
                     st.synchronize()
-                    cpu = frames[k].cpu()
-                    plans[k].gather(cpu, dist)
-                    frames[k].copy_(cpu)
+                    cpu = frames[k][:count].cpu()
+                    mine = plans[k].assemble(cpu, dist)
+                    frames[k][:count].copy_(cpu)
             if feat.enableBloomEffect:
-                api.bloom_device(frames[k].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
-                                 feat.bloomFilterIntensity, stream=st.cuda_stream)
-            host[k].copy_(frames[k], non_blocking=True)
+                for f in mine:
+                    api.bloom_device(frames[k][f].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
+                                     feat.bloomFilterIntensity, stream=st.cuda_stream)
+            if world == 1:
+                host[k][:count].copy_(frames[k][:count], non_blocking=True)
+            else:
+                for f in mine:
+                    host[k][f].copy_(frames[k][f], non_blocking=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not a step: every stream's frame buffers are allocated by its first frame, and a frame whose deferred tasks
-    # overflow the default queue sizes (many glossy samples) makes the scene allocate larger ones for the frames after it
+    # set-up, not a step: every stream's frame buffers are allocated by its first sequence, and frames whose deferred tasks
+    # overflow the default queue sizes (many glossy samples) make the scene allocate larger ones for the frames after them
     for attempt in range(4):
         for i in range(F):
-            step(i, cams[i % len(cams)] if cams else None)
+            run(i, i * K, K)
         barrier()
         again = False
         for k in range(F):
@@ -221,17 +240,19 @@ def main():
                 again = True
         if not again:
             break
-    for i in range(args.warmup):
-        step(i, cams[i % len(cams)] if cams else None)
+    for i, (first, count) in enumerate(sequences(args.warmup)):
+        run(i, first, count)
     barrier()
-    stats = scene.sync(streams[0].cuda_stream)  # this rank's share of one frame
-    timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    stats = scene.sync(streams[0].cuda_stream)  # this rank's share of the last sequence queued on stream 0
+    stats_frames = last_count[0]
+    timed = sequences(args.steps)
+    timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, cams[i] if cams else None, timed_ev[i])
+    for i, (first, count) in enumerate(timed):
+        run(i, first, count, timed_ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    launch_ms_timed = float(np.mean([a.elapsed_time(b) for a, b in timed_ev]))  # one rt_render launch sequence among the others in flight
+    launch_ms_timed = float(np.mean([a.elapsed_time(b) for a, b in timed_ev]))  # one launch sequence among the others in flight
 
     # one frame with nothing else queued: its latency, and the duration of the rt_render launch sequence by itself
     # (events on the stream the launches run on)
@@ -240,7 +261,7 @@ def main():
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step(i, cams[i % len(cams)] if cams else None, ev, flags)
+        run(0, i, 1, ev, flags)
         torch.cuda.synchronize()
         alone.append((time.perf_counter() - t1) * 1e3)
         kernel_ms.append(ev[0].elapsed_time(ev[1]))
@@ -256,7 +277,7 @@ def main():
                 tot[k] += v / len(cams)
         rays_rank = torch.tensor(tot, dtype=torch.float64)
     else:
-        rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64)
+        rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64) / stats_frames
     tmax = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         if args.backend == "nccl":
@@ -274,14 +295,17 @@ def main():
     # which visits every box a ray enters (no culling, the caller's tree, 36 B per test), is reported beside it and is not
     # the basis of `achieved`.
     def counted(fl, schedule):
-        scene.render_device(cam, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region,
-                            flags=fl | (api.RT_RENDER_COUNT_SCHEDULE if schedule else api.RT_RENDER_COUNT_WORK), stream=s0)
+        n = K if schedule else 1  # the schedule of a sequence depends on how many frames share its launches
+        scene.render_frames_device([cam] * n, feat, W, H, wl["start_depth"], frames[0].data_ptr(), region=region,
+                                   flags=fl | (api.RT_RENDER_COUNT_SCHEDULE if schedule else api.RT_RENDER_COUNT_WORK), stream=s0)
         wk = scene.sync(s0)
+        for name in ("queryNodeSteps", "nodePairSteps", "triangleTests", "primaryRays", "shadowRays", "secondaryRays", "pixels"):
+            setattr(wk, name, getattr(wk, name) // n)
         tri_b = 48.0 if schedule else 36.0
         return wk, 128.0 * wk.queryNodeSteps + 64.0 * wk.nodePairSteps + tri_b * wk.triangleTests + 44.0 * wk.rays + 12.0 * wk.pixels
     try:
-        work, alg_bytes = counted(flags, True)
-        counted_what = "the frame as scheduled (query tree, candidate batches, second traces)"
+        work, alg_bytes = counted(flags_timed, True)
+        counted_what = "one frame of a launch sequence as scheduled and timed (query tree, candidate batches, second traces)"
     except api.RtError:  # schedules without counters (a pixel per lane): the reference's rays in the caller's tree, culled
         try:
             work, alg_bytes = counted(flags, False)
@@ -323,17 +347,19 @@ def main():
             "mrays_per_s_one_frame_alone": rays_frame / world / alone_ms / 1e3 if world == 1 else None,
             "config": {"workload": args.workload, "description": wl["desc"], "width": W, "height": H,
                        "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
-                       "rays_per_frame": int(rays_frame), "frames_in_flight": F,
+                       "rays_per_frame": int(rays_frame), "frames_per_sequence": K, "sequences_in_flight": F, "frames_in_flight": K * F,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "step": "rt_render" + (" + stripe all-gather" if world > 1 else "") + " + rt_bloom + frame copy to pinned host memory",
-                       "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-gather" if world > 1 else ""),
+                       "step": "one frame: its share of rt_render_frames" + (" + stripe all-to-all (frame f whole on rank f % N)" if world > 1 else "")
+                               + " + rt_bloom + frame copy to pinned host memory",
+                       "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-to-all" if world > 1 else ""),
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": "rt_render launch sequence of one frame (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
-                         "note": "achieved = algorithmic bytes of one launch sequence x steps / elapsed time of the timed region (frames_in_flight "
-                                 "sequences share the GPU); launch_ms_timed = mean duration of one sequence there, kernel_ms = alone, both from "
-                                 "events on the sequence's stream",
+                         "kernel": "launch sequence of rt_render_frames (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
+                         "note": "achieved = algorithmic bytes of one frame x steps / elapsed time of the timed region (sequences_in_flight "
+                                 "launch sequences of frames_per_sequence frames share the GPU); launch_ms_timed = mean duration of one such "
+                                 "sequence there, kernel_ms = the launch sequence of ONE frame alone (rt_render), both from events on the "
+                                 "sequence's stream",
                          "launch_ms_timed": launch_ms_timed, "kernel_ms": kernel_ms, "achieved_one_launch_alone": achieved_alone,
                          "algorithmic_bytes_per_launch": alg_bytes, "counted": counted_what,
                          "query_nodes_per_ray": work.queryNodeSteps / max(work.rays, 1),

@@ -8,6 +8,10 @@ all-gather of finished stripes (RCCL on GPUs, gloo in the CPU tests).  Bloom nee
 
 Frames are in Screen order: memory row m holds image row H-1-m (src/screen.cpp:119-122), so image
 stripe s is memory row block n_stripes-1-s when H is a multiple of stripe_rows.
+
+Two exchanges: `gather` leaves the whole frame on every rank (one all-gather); `assemble` takes the K frames of
+one launch sequence (rt_render_frames) and leaves frame f whole on rank f % world only (one all-to-all: every rank
+sends each stripe once instead of world - 1 times), so that bloom and the copy to the host happen once per frame.
 """
 import torch
 
@@ -42,3 +46,31 @@ class StripePlan:
         self.send[: len(self.mine)] = blocks[self.my_blocks]
         dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
         blocks[self.all_blocks] = self.recv.permute(1, 0, 2).reshape(self.per_rank * self.world, -1)[: self.n_stripes]
+
+    def root_of(self, frame_index: int) -> int:
+        """The rank on which `assemble` leaves frame `frame_index` of a sequence."""
+        return frame_index % self.world
+
+    def assemble(self, frames: torch.Tensor, dist) -> list:
+        """frames: (K, H, W, C) Screen-order tensor holding this rank's stripes of K frames.  On return the frames
+        f with f % world == rank hold every rank's stripes; the others are unchanged.  Returns those f."""
+        K = frames.shape[0]
+        mine_f = list(range(self.rank, K, self.world))
+        if self.world == 1:
+            return mine_f
+        per_root = (K + self.world - 1) // self.world                    # frames a rank is the root of (padded)
+        key = (K, frames.device, frames.dtype)
+        if getattr(self, "_a2a_key", None) != key:
+            shape = (per_root, self.world, self.per_rank, self.block)    # [j, destination]: frame j * world + destination
+            self._a2a_stage = torch.zeros(shape, dtype=frames.dtype, device=frames.device)
+            self._a2a_send = torch.zeros((self.world, per_root, self.per_rank, self.block), dtype=frames.dtype, device=frames.device)
+            self._a2a_recv = torch.zeros_like(self._a2a_send)                 # [source, j]
+            self._a2a_key = key
+        blocks = frames.view(K, self.n_stripes, self.block)
+        self._a2a_stage.view(per_root * self.world, self.per_rank, self.block)[:K, : len(self.mine)] = blocks[:, self.my_blocks]
+        self._a2a_send.copy_(self._a2a_stage.permute(1, 0, 2, 3))
+        dist.all_to_all_single(self._a2a_recv.view(-1), self._a2a_send.view(-1))
+        for j, f in enumerate(mine_f):
+            # recv[s, j, p] is stripe p * world + s of frame f
+            blocks[f][self.all_blocks] = self._a2a_recv[:, j].permute(1, 0, 2).reshape(self.per_rank * self.world, -1)[: self.n_stripes]
+        return mine_f

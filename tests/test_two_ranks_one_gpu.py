@@ -1,6 +1,6 @@
 """The multi-rank render path executed end to end on one GPU: two fresh processes share GPU 0 and exchange
 their stripes over gloo (host memory).  What runs is the code the N > 1 launch runs: rt_render with an
-rt_region per rank, StripePlan's all-gather, bloom on the gathered frame; only the transport differs from
+rt_region per rank, StripePlan's all-gather, bloom on the gathered frame (and rt_render_frames with StripePlan's all-to-all); only the transport differs from
 RCCL.  No scaling figure comes out of this: two ranks on one GPU time-share it."""
 import json
 import os
@@ -37,6 +37,7 @@ def test_two_ranks_render_stripes_and_gather_the_one_call_frame(tmp_path):
     assert res["lit"] > 1000
     assert res["equal"], f"{res['differing']} values differ from the one-call frame"
     assert res["rays"] == res["rays_one_call"]     # the ranks' ray counts add up to the frame's
+    assert res["sequence_frames_equal"]            # three frames in one launch sequence, each assembled on its root rank
 
 
 def test_bench_runs_with_two_ranks_over_gloo():

@@ -53,6 +53,29 @@ def main():
     rays = torch.tensor([st.primaryRays, st.shadowRays, st.secondaryRays, st.pixels], dtype=torch.int64)
     dist.all_reduce(rays)
     result = {"foreign_rows_written": int(foreign.sum())}
+
+    # a launch sequence of three frames (rt_render_frames), three cameras: this rank's stripes of every frame, then one
+    # all-to-all that leaves frame f whole on rank f % world, which blooms it; each root compares its frames with the
+    # frames one rt_render call per camera produces
+    cams = [api.camera_from_trackball(W, H, rot_deg=(20.0, 20.0 + 50.0 * k, 0.0)) for k in range(3)]
+    seq = torch.zeros((len(cams), H, W, 3), dtype=torch.float32, device=dev)
+    scene.render_frames_device(cams, feat, W, H, 3, seq.data_ptr(), region=api.Region(8, rank, world), stream=0)
+    scene.sync(0)
+    cpu = seq.cpu()
+    roots = plan.assemble(cpu, dist)
+    seq.copy_(cpu)
+    seq_equal = roots == [f for f in range(len(cams)) if f % world == rank]
+    for f in roots:
+        bloom(seq[f])
+        whole = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        scene.render_device(cams[f], feat, W, H, 3, whole.data_ptr(), stream=0)
+        scene.sync(0)
+        bloom(whole)
+        torch.cuda.synchronize()
+        seq_equal = seq_equal and bool(torch.equal(seq[f].view(torch.int32), whole.view(torch.int32))) and bool((whole > 0).sum() > 1000)
+    seq_flag = torch.tensor([1 if seq_equal else 0])
+    dist.all_reduce(seq_flag, op=dist.ReduceOp.MIN)
+    result["sequence_frames_equal"] = bool(seq_flag.item())
     if rank == 0:
         whole = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
         scene.render_device(cam, feat, W, H, 3, whole.data_ptr(), region=api.Region(8, 0, 1), stream=0)

@@ -13,7 +13,7 @@ cut -c1-200 $out/bench.json
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
 # per-kernel durations of frames rendered one at a time: they add up to the frame's time alone
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 $root/bench.py --frames-in-flight 1 --steps 5 --warmup 1 --cpu-seconds 0 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 $root/bench.py --frames-in-flight 1 --frames-per-sequence 1 --steps 5 --warmup 1 --cpu-seconds 0 > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 cp $out/kt/p_kernel_stats.csv $out/kernel_stats.csv
 grep -h '"metric"' $out/kt.log > $out/bench_under_rocprof.json
 # the same with the bench's default frames in flight: kernels of different frames overlap, durations stretch
