@@ -174,6 +174,7 @@ def main():
 
     F = max(1, min(8, args.frames_in_flight))
     K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence, -(-max(args.steps, 1) // F)))  # frames per launch sequence
+    K = max(1, min(K, (8 * 1920 * 1080) // (W * H)))  # ... within 16.6 M pixels (about 3 KB of queues and path states per pixel)
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     frames = [torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]

@@ -120,6 +120,12 @@ struct rt_scene {
                                      // on to the group launch (0: no second pass; RT_AMD_QBUDGET2, RT_AMD_QBUDGET2_OVERLAPPED)
     uint32_t laneModeAboveOverlapped = 65536, queryStepBudgetOverlapped = 20; // the same two for frames that overlap with others
                                      // (RT_RENDER_OVERLAPPED; RT_AMD_T1_OVERLAPPED, RT_AMD_QBUDGET_OVERLAPPED)
+    // Launch sequences over many pixels (several frames rendered together, or one very large frame): every round holds so many rays
+    // that its fixed costs no longer count, and what pays is fewer rays - candidate batches of two children (three candidates for
+    // two rays instead of ten for four, in twice the rounds) - and fewer rays handed over (a longer walk before a lane gives up).
+    uint32_t largeFromPixels = 6000000;   // RT_AMD_LARGE_FROM (pixels of the sequence's region; 0 = never)
+    uint32_t batchWindowLarge = 2;        // RT_AMD_BATCH_WINDOW_LARGE
+    uint32_t queryStepBudgetLarge = 32;   // RT_AMD_QBUDGET_LARGE
     bool quadTrace = false;          // group launches in a query tree run four lanes per ray (RT_AMD_QUAD_TRACE; default: 8 or 16)
     int pathQuads = 0;               // pixel-per-lane mode with a query tree: 1 = four lanes per pixel (frames in LDS), 2 = the same with frames in
                                      // global memory, 0 = one lane per pixel (RT_AMD_PATH_QUADS)
@@ -1809,6 +1815,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_QBUDGET2")) s->secondPassBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET2_OVERLAPPED")) s->secondPassBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
+    if (const char* e = getenv("RT_AMD_LARGE_FROM")) s->largeFromPixels = (uint32_t)atoll(e);
+    if (const char* e = getenv("RT_AMD_BATCH_WINDOW_LARGE")) s->batchWindowLarge = (uint32_t)std::min(5, std::max(0, atoi(e)));
+    if (const char* e = getenv("RT_AMD_QBUDGET_LARGE")) s->queryStepBudgetLarge = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_GROUP_LANES")) {
         const int g = atoi(e);
         if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) s->groupLanes = (uint32_t)g;
@@ -1935,7 +1944,9 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     // a frame that shares the GPU with others: one ray per lane (cheaper per ray, slower for the stage's longest ray) from fewer rays on
     const bool overlapped = (flags & RT_RENDER_OVERLAPPED) != 0;
     const uint32_t laneModeAbove = overlapped ? scene->laneModeAboveOverlapped : scene->laneModeAbove;
-    const uint32_t queryStepBudget = overlapped ? scene->queryStepBudgetOverlapped : scene->queryStepBudget;
+    const bool large = scene->largeFromPixels != 0 && nWork >= scene->largeFromPixels;
+    const uint32_t queryStepBudget = large ? scene->queryStepBudgetLarge : (overlapped ? scene->queryStepBudgetOverlapped : scene->queryStepBudget);
+    const uint32_t sceneBatchWindow = large ? std::min(scene->batchWindow, scene->batchWindowLarge) : scene->batchWindow;
     const uint32_t fullGrid = (nWork + kBlock - 1) / kBlock;
     uint32_t grid = (uint32_t)scene->numCUs * 4u; // persistent: 4 workgroups per CU
     if (grid > fullGrid) grid = fullGrid;
@@ -2038,9 +2049,9 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         bool area = false;
         for (int ty : scene->lightTypes) area = area || ty != 0;
         const uint32_t N = features->numGlossySamples;
-        if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && scene->batchWindow >= 2
+        if (features->enableReflections && features->enableGlossyReflection && !area && N >= 2 && sceneBatchWindow >= 2
             && startDepth <= RT_MAX_RAY_DEPTH - 2 && !countRef && !features->enableTransparency) { // a counting pass walks only the reference's rays
-            batchWindow = std::min(N, scene->batchWindow);
+            batchWindow = std::min(N, sceneBatchWindow);
             batchRays = batchWindow * (batchWindow + 1) / 2;
         }
     }
