@@ -109,6 +109,7 @@ struct rt_scene {
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
                                     // RT_AMD_NO_BATCH: one child per round; at most 5)
     bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
+    bool noShadowBound = false;     // RT_AMD_NO_SHADOW_BOUND: shadow rays are traced to their closest hit like every other ray
     uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
@@ -1815,6 +1816,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_QBUDGET2")) s->secondPassBudget = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET2_OVERLAPPED")) s->secondPassBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
+    if (getenv("RT_AMD_NO_SHADOW_BOUND")) s->noShadowBound = true;
     if (const char* e = getenv("RT_AMD_LARGE_FROM")) s->largeFromPixels = (uint32_t)atoll(e);
     if (const char* e = getenv("RT_AMD_BATCH_WINDOW_LARGE")) s->batchWindowLarge = (uint32_t)std::min(5, std::max(0, atoi(e)));
     if (const char* e = getenv("RT_AMD_QBUDGET_LARGE")) s->queryStepBudgetLarge = (uint32_t)atoi(e);
@@ -2219,11 +2221,26 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
                                                        : (laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     uint32_t gridNow = groupGrid; // workgroups of the next group launch: fewer where few rays are expected (the rest is fetched in chunks)
+    bool anyHit = false; // the stage being launched holds shadow rays whose tag word is the shaded point's distance (see any_bound)
     auto launch_one = [&](uint32_t groupLanes, bool query) {
         T.fetch = w.d_roundCounts + nextFetch++;
         T.S = query ? scene->queryView : scene->view;
         if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
+            if (anyHit && !scene->quadTrace) {
+                if (count) {
+                    if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, true, 8, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                    else if (groupLanes == 16)
+                        hipLaunchKernelGGL((group_trace_kernel<true, true, 16, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                    else hipLaunchKernelGGL((trace_kernel<true, true, 16, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+                    return;
+                }
+                if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                else if (groupLanes == 16)
+                    hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
+                else hipLaunchKernelGGL((trace_kernel<true, false, 16, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+                return;
+            }
             if (groupLanes >= 8 && scene->quadTrace && scene->queryView.quadNodes && !count) { // four lanes per ray instead
                 hipLaunchKernelGGL(quad_trace_kernel, dim3(std::max(1u, gridNow * 4u / groupLanes)), dim3(kBlock), 0, st, T);
                 return;
@@ -2485,7 +2502,9 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
                 else RT_WALK_CASE(false, true);
 #undef RT_WALK_CASE
             } else {
+                anyHit = !scene->noShadowBound;
                 launch_trace(w.d_shadowRays, sizeof(RayRec), P.qCount + 0, P.chunkBase, P.chunkTasks, raysPerTask, false, 0, 2);
+                anyHit = false;
             }
             P.hits = static_cast<const HitRec*>(w.d_hits);
         } else {

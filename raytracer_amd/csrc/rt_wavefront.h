@@ -361,6 +361,17 @@ __device__ __forceinline__ void lane_node4_step(const SceneView& S, TraceLane& T
 // stack is empty) - a wave then runs the long triangle code for many lanes at once instead of for the one or
 // two that happen to be at a leaf.  Leaves are still tested in the order they are reached, so equal-distance
 // ties fall as in the reference.  Returns true for lanes whose query has ended.
+// Shadow queries (ANY).  visibilityOfLightSampleBinary (src/light.cpp:66-90) only asks whether the closest hit of the ray from the
+// light lies within 5e-4 of the shaded point's distance D.  A ray record whose tag word holds D lets a query-tree launch answer
+// that with less work: nothing beyond any_bound(D) can be the hit that makes the sample visible, so the walk starts with that
+// as its closest distance (after the root test, which the reference makes with the ray's own t), and a triangle closer than
+// any_occluded(D) settles the answer at once - the reference's closest hit is then at most that far, and the distance test
+// fails for it as it fails for this one.  The record that comes out is {t, triangle} of A hit the reference also finds (same
+// proof as for every query-tree result), or no hit: the visibility test on it gives the reference's answer.  Equal distances
+// need no care here (the answer depends on t alone).  Launches that ignore the tag return the closest hit itself.
+__device__ __forceinline__ float any_bound(const float D) { return (D + 2e-3f) * 1.000001f; }
+__device__ __forceinline__ float any_occluded(const float D) { return (D - 2e-3f) * 0.999999f; }
+
 #ifndef RT_LEAF_BATCH
 #define RT_LEAF_BATCH 20
 #endif
@@ -369,7 +380,7 @@ constexpr int kLeafBatch = RT_LEAF_BATCH;
 #define RT_STUCK_LANES 8
 #endif
 constexpr int kStuckLanes = RT_STUCK_LANES; // lanes that cannot go on without their leaf test before the wave runs it
-template <bool CULL, bool COUNT, int STACK, bool QUERY>
+template <bool CULL, bool COUNT, int STACK, bool QUERY, bool ANY = false>
 __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool has, TraceLane& T, uint32_t* const stack, TraceCounters& tc)
 {
     if (has && T.cur != kTraversalDone && !(T.cur & kLeafBit)) {
@@ -389,8 +400,9 @@ __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool h
     if (test) {
         if (parked) {
             const uint32_t first = T.pend & kRefOffsetMask, cnt = (T.pend >> kRefCountShift) & kMaxLeafCount;
-            leaf_test_narrow<COUNT, QUERY>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc, &T.tieT);
+            leaf_test_narrow<COUNT, QUERY && !ANY>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc, &T.tieT);
             T.pend = 0;
+            if (ANY && T.t < T.tieT) T.cur = kTraversalDone, T.sp = 0; // (tieT holds any_occluded(D) here) an occluder: the answer is settled
         }
     }
     if (has && T.cur == kTraversalDone && T.pend == 0) {
@@ -444,7 +456,7 @@ constexpr int kRefillLanes = RT_REFILL_LANES; // idle lanes a wave waits for bef
 constexpr uint32_t kLaneChunk = 64;  // rays a wave takes from the shared counter at a time
 constexpr uint32_t kGroupChunk = 32; // the same for a wave whose lanes share rays
 
-template <bool CULL, bool COUNT, int STACK, bool QUERY = false>
+template <bool CULL, bool COUNT, int STACK, bool QUERY = false, bool ANY = false>
 __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const TraceParams P)
 {
     __shared__ uint32_t s_stack[2 * STACK * kBlock]; // per lane: STACK node references, then their entry distances
@@ -499,6 +511,7 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
                 steps = 0;
                 if (!has) P.hits[idx] = HitRec { T.t, T.tri };
                 if (QUERY && has && !T.R.approx) unfit = true, has = false; // the conservative tests need the approximate slabs
+                if (ANY && has) T.t = fminf(T.t, any_bound(b.w)), T.tieT = any_occluded(b.w); // the tag word holds the shaded point's distance
             }
             if (QUERY && __ballot(unfit) != 0ull) {
                 const uint32_t pos = wave_fetch(P.fallCount, unfit, lane);
@@ -511,11 +524,11 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
         }
 #pragma unroll 1
         for (int it = 0; it < kStepsPerCheck; it++) {
-            const bool ended = trace_wave_step<CULL, COUNT, STACK, QUERY>(S, has, T, stack, tc);
+            const bool ended = trace_wave_step<CULL, COUNT, STACK, QUERY, ANY>(S, has, T, stack, tc);
             bool unproven = false;
             if (ended) {
                 if (QUERY) {
-                    unproven = !query_result_proven(S, T.R, T.t, T.tri, T.tieT, T.lost);
+                    unproven = !query_result_proven(S, T.R, T.t, T.tri, ANY ? -1.0f : T.tieT, T.lost);
                     for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
                         if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
                 }
@@ -1520,7 +1533,7 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
 }
 
 // Leaf step for the groups with `active`: pop up to G leaves, test their triangles, refresh the group's best.
-template <bool COUNT, int G, bool QUERY>
+template <bool COUNT, int G, bool QUERY, bool ANY = false>
 __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const bool active,
                                                 TraceCounters& tc)
 {
@@ -1534,11 +1547,11 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
         float tl = T.cullT; // the closest hit any lane of the group holds: nothing beyond it can win (equal distances stay in)
         uint32_t tril = kNoHit;
         // query-tree launches: one triangle in flight at a time keeps the kernel free of register spills at 4 waves per SIMD
-        if (QUERY) leaf_test_narrow<COUNT, true>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
+        if (QUERY) leaf_test_narrow<COUNT, !ANY>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
         else leaf_test<COUNT, false>(S, first, cnt, T.R.o, T.R.d, tl, tril, tc, &T.tieT);
         if (tril != kNoHit) {
             if (QUERY) { // the walk's order means nothing here: equal distances are only noted
-                if (tl == T.bestT && T.bestTri != kNoHit) T.tieT = tl;
+                if (!ANY && tl == T.bestT && T.bestTri != kNoHit) T.tieT = tl;
                 T.bestT = tl, T.bestTri = tril;
             } else {
                 const uint32_t aligned = key << __clz(key);
@@ -1552,6 +1565,7 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
     if (active) T.cullT = bt;
+    if (ANY && active && bt < T.tieT) T.nq = 0, T.lq = 0; // (tieT holds any_occluded(D) here) an occluder: the answer is settled
 }
 
 // The group's result on every lane of the group (all lanes of the wave must call).
@@ -1574,7 +1588,7 @@ __device__ __forceinline__ void group_finish(const SceneView& S, GroupLane& T, c
 
 // The same for a query-tree launch: the closest triangle of the group, and whether the reference provably reports it
 // (query_result_proven; two lanes holding different triangles at the closest distance are a tie as well).
-template <int G>
+template <int G, bool ANY = false>
 __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane& T, const int groupShift, const bool active)
 {
     constexpr uint32_t kGroupMask = (uint32_t)((1ull << G) - 1ull);
@@ -1582,12 +1596,13 @@ __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) bt = fminf(bt, __shfl_xor(bt, off));
     const uint32_t holders = (uint32_t)(__ballot(T.bestTri != kNoHit && T.bestT == bt) >> groupShift) & kGroupMask;
-    const uint32_t tied = (uint32_t)(__ballot(T.tieT == bt) >> groupShift) & kGroupMask;
+    const uint32_t tied = ANY ? 0u : (uint32_t)(__ballot(T.tieT == bt) >> groupShift) & kGroupMask;
     const int winner = holders ? __ffs(holders) - 1 : 0;
     uint32_t bi = __shfl(T.bestTri, groupShift + winner);
     if (!holders) bi = kNoHit;
     if (!active) return true;
-    const bool proven = __popc(holders) <= 1 && tied == 0u && query_result_proven(S, T.R, bt, bi, -1.0f, 0u);
+    // (a shadow query asks for the distance alone: which of several triangles at the closest distance is reported does not matter)
+    const bool proven = (ANY || __popc(holders) <= 1) && tied == 0u && query_result_proven(S, T.R, bt, bi, -1.0f, 0u);
     T.bestT = bt, T.bestTri = bi;
     for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
         if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.bestT)) T.bestTri = kSphereBase + s;
@@ -1596,7 +1611,7 @@ __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane
 
 // trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
 // full stack can always be walked one entry at a time.
-template <bool CULL, bool COUNT, int G, bool QUERY = false>
+template <bool CULL, bool COUNT, int G, bool QUERY = false, bool ANY = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
     using Lay = GroupLayout<G, !QUERY>;
@@ -1655,6 +1670,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 has = group_begin<G, QUERY>(S, T, q, j, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w);
                 if (!has && j == 0) P.hits[idx] = HitRec { T.bestT, kNoHit };
                 if (QUERY && has && !T.R.approx) unfit = true, has = false; // the conservative tests need the approximate slabs
+                if (ANY && has) T.bestT = T.cullT = fminf(T.bestT, any_bound(b.w)), T.tieT = any_occluded(b.w); // the tag word holds the shaded point's distance
             }
             if (QUERY && __ballot(unfit) != 0ull) {
                 const uint32_t pos = wave_fetch(P.fallCount, unfit && j == 0, lane);
@@ -1674,11 +1690,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             if (__ballot(needNode) != 0ull)
                 group_node_step<CULL, COUNT, G, QUERY>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
             if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull)
-                group_leaf_step<COUNT, G, QUERY>(S, T, q, j, has && T.lq > 0, tc);
+                group_leaf_step<COUNT, G, QUERY, ANY>(S, T, q, j, has && T.lq > 0, tc);
             const bool done = has && T.nq == 0 && T.lq == 0;
             if (__ballot(done) != 0ull) {
                 bool proven = true;
-                if (QUERY) proven = group_finish_query<G>(S, T, groupShift, done);
+                if (QUERY) proven = group_finish_query<G, ANY>(S, T, groupShift, done);
                 else group_finish<G>(S, T, done);
                 if (done) {
                     if (j == 0 && proven) P.hits[idx] = HitRec { T.bestT, T.bestTri };
@@ -1849,7 +1865,8 @@ __global__ __launch_bounds__(kBlock) void shadow_gen_kernel(const WaveParams P)
             continue;
         }
         for_each_light_sample(P.S, P.F, __float_as_uint(a.z), [&](const uint32_t j, int, bool, const vec3 lpos, const vec3) {
-            store_ray(out + j, lpos, normalize(p - lpos), FLT_MAX, 0u);
+            // the tag word: the distance shade_logic_kernel will compare the hit with (see any_bound)
+            store_ray(out + j, lpos, normalize(p - lpos), FLT_MAX, __float_as_uint(length(p - lpos)));
             cShadow++;
         });
     }

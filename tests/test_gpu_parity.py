@@ -554,12 +554,15 @@ def test_unnested_caller_tree_is_walked_as_given():
                                    dict(RT_AMD_PATH_MODE="1"), dict(RT_AMD_PATH_MODE="1", RT_AMD_GROUP_LANES="16"), dict(RT_AMD_PATH_MODE="2"),
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_NO_QUERY_TREE="1"), dict(RT_AMD_PATH_MODE="2", RT_AMD_SCATTER="1"),
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_LINK_BUDGET="3", RT_AMD_MIN_LANES="48"), dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="1"),
-                                   dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="2", RT_AMD_ADVANCE_AT="4"), dict(RT_AMD_QUAD_TRACE="1")])
+                                   dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="2", RT_AMD_ADVANCE_AT="4"), dict(RT_AMD_QUAD_TRACE="1"),
+                                   dict(RT_AMD_NO_SHADOW_BOUND="1"), dict(RT_AMD_NO_SHADOW_BOUND="1", RT_AMD_T1="1", RT_AMD_QBUDGET="2"),
+                                   dict(RT_AMD_T1="1", RT_AMD_QBUDGET="1"), dict(RT_AMD_LARGE_FROM="1"), dict(RT_AMD_LARGE_FROM="1", RT_AMD_T1="1")])
 def test_tuning_knobs_change_nothing(knobs, monkeypatch):
     """Every schedule the tuning knobs select (one ray per lane with rays handed over after a few steps, other group
     widths, no candidate batches, another query tree, the path stage as one persistent launch per pixel group, lane or
-    quad instead of frame-wide rounds) renders the frame of the default schedule bit for bit: small scenes never reach
-    the ray counts at which the default switches schedules by itself."""
+    quad instead of frame-wide rounds, shadow rays traced to their closest hit instead of as bounded queries that stop at
+    the first occluder, the settings of large launch sequences) renders the frame of the default schedule bit for bit:
+    small scenes never reach the ray counts at which the default switches schedules by itself."""
     _, _, sc = scene_pair("knot")
     W, H = 320, 180
     fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)

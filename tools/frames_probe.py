@@ -15,6 +15,8 @@ W, H = wl.get("width", 1920), wl.get("height", 1080)
 world = int(os.environ.get("RT_PROBE_WORLD", "1"))
 sc = bench.build_scene_arrays(wl["scene"], None)
 fkw = dict(bench.FEATURE_BASE); fkw.update(wl["feat"])
+if os.environ.get("RT_PROBE_NO_SHADOWS"):
+    fkw["enableShadows"] = 0
 feat = api.Features(**fkw)
 cam = api.camera_from_trackball(W, H)
 dev = torch.device("cuda", 0)
