@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0: leave the environment's value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
+    ap.add_argument("--keep-pooling", action="store_true", help="pool --frames-per-sequence frames even when a frame renders in under 3 ms")
+    ap.add_argument("--sequence-sizes", default="", help="frames of the timed launch sequences, in queue order (comma list; default: see sequences())")
     args = ap.parse_args()
 
     # Streams map onto the HIP runtime's hardware queues, 4 per process by default: with 4 frame streams next to the null
@@ -174,6 +176,26 @@ def main():
 
     F = max(1, min(8, args.frames_in_flight))
     K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence, -(-max(args.steps, 1) // F)))  # frames per launch sequence
+    if args.sequence_sizes:
+        K = max(1, min(api.RT_MAX_FRAMES, max(int(x) for x in args.sequence_sizes.split(","))))
+    elif K > 2 and not args.keep_pooling:
+        # Frames that render faster than a few copies of a frame to the host (25 MB: 0.45 ms) are bound by those copies, and
+        # long sequences only bunch the copies up: such frames go two at a time.  Measured here, before anything is timed.
+        probe = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            scene.render_device(cam, feat, W, H, wl["start_depth"], probe.data_ptr(), region=region, flags=flags, stream=0)
+            try:
+                scene.sync(0)
+            except api.RtError as e:  # queues growing: a heavy frame
+                if e.code != api.RT_ERR_AGAIN:
+                    raise
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        scene.render_device(cam, feat, W, H, wl["start_depth"], probe.data_ptr(), region=region, flags=flags, stream=0)
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t1) * 1e3 < 3.0:
+            K = 2
+        del probe
     K = max(1, min(K, (8 * 1920 * 1080) // (W * H)))  # ... within 16.6 M pixels (about 3 KB of queues and path states per pixel)
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
@@ -247,6 +269,11 @@ def main():
     stats = scene.sync(streams[0].cuda_stream)  # this rank's share of the last sequence queued on stream 0
     stats_frames = last_count[0]
     timed = sequences(args.steps)
+    if args.sequence_sizes:
+        sizes = [int(x) for x in args.sequence_sizes.split(",")]
+        if sum(sizes) != args.steps or max(sizes) > K or min(sizes) < 1:
+            raise SystemExit(f"--sequence-sizes must add up to {args.steps} steps, each within 1..{K}")
+        timed = [(sum(sizes[:i]), n) for i, n in enumerate(sizes)]
     timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
     t0 = time.perf_counter()
     for i, (first, count) in enumerate(timed):

@@ -233,6 +233,13 @@ int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);
 int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features* features, int width, int height,
                     int startDepth, uint32_t flags, float* rgb, uint32_t* primId, float* primT, rt_stats* stats);
 
+/* The loop over cameras of src/main.cpp:515-526 for host callers: frame f of nFrames (any number) is rendered from
+ * cameras[f] into rgb[f] (HOST, W*H*3 floats = that frame's Screen::pixels()), bloom included when enabled.  The frames
+ * are rendered by rt_render_frames, up to eight at a time; every image is the one rt_render_image writes for its camera.
+ * stats: the counters of all frames together. */
+int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width,
+                     int height, int startDepth, uint32_t flags, float* const* rgb, rt_stats* stats);
+
 /* BVHInterface::intersect (src/bvh_interface.h:61) for a batch of rays on the GPU.
  * rays: HOST n x 7 floats {origin3, direction3, t}; t is updated in place.
  * hits: HOST n x 12 dwords {normal3, barycentric3, texCoord2 (floats), primId, meshID, hit(0/1), 0}. */

@@ -121,6 +121,8 @@ def lib():
     L.rt_sync.argtypes = [vp, vp, C.POINTER(Stats)]
     L.rt_render_image.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.c_uint32, f32p, u32p,
                                   f32p, C.POINTER(Stats)]
+    L.rt_render_images.argtypes = [vp, C.POINTER(Camera), C.c_int, C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(f32p),
+                                   C.POINTER(Stats)]
     L.rt_intersect.argtypes = [vp, C.POINTER(Features), f32p, C.c_uint32, vp]
     L.rt_selftest_division.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rt_selftest_query_tree.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -249,6 +251,14 @@ class Scene:
         check(lib().rt_render_image(self.h, C.byref(cam), C.byref(features), W, H, start_depth, flags, _p(rgb, f32p), _p(pid, u32p),
                                     _p(pt, f32p), C.byref(st)))
         return dict(rgb=rgb, prim=pid, t=pt, stats=st)
+
+    def render_images(self, cams, features, W, H, start_depth=0, flags=0):
+        """rt_render_images: one host image per camera (the reference's loop over cameras), rendered several frames at a time."""
+        rgb = np.zeros((len(cams), H, W, 3), np.float32)
+        ptrs = (f32p * len(cams))(*[rgb[k].ctypes.data_as(f32p) for k in range(len(cams))])
+        st = Stats()
+        check(lib().rt_render_images(self.h, (Camera * len(cams))(*cams), len(cams), C.byref(features), W, H, start_depth, flags, ptrs, C.byref(st)))
+        return dict(rgb=rgb, stats=st)
 
     def render_device(self, cam, features, W, H, start_depth, d_rgb, d_prim=None, d_t=None, region=None, flags=0, stream=None):
         """rt_render on caller-owned device memory (integers = device addresses). Asynchronous."""

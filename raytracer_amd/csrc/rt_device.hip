@@ -2817,6 +2817,62 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
     return RT_OK;
 }
 
+int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width, int height, int startDepth,
+                     uint32_t flags, float* const* rgb, rt_stats* stats)
+{
+    if (!scene || !cameras || !rgb || !features || width <= 0 || height <= 0 || nFrames < 1) {
+        rt::set_error("rt_render_images: null argument, no frame or empty frames");
+        return RT_ERR_INVALID;
+    }
+    for (int f = 0; f < nFrames; f++)
+        if (!rgb[f]) {
+            rt::set_error("rt_render_images: frame %d has no image", f);
+            return RT_ERR_INVALID;
+        }
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t px = (size_t)width * height;
+    // launch sequences of up to 8 frames and 16.6 M pixels: about 3 KB of task queues and path states per pixel
+    const int perSequence = (int)std::max<size_t>(1, std::min<size_t>(std::min(nFrames, 8), (size_t)(8 * 1920 * 1080) / px));
+    if (px * perSequence > scene->fbPixels) {
+        (void)hipFree(scene->d_rgb), (void)hipFree(scene->d_scratch), (void)hipFree(scene->d_primId), (void)hipFree(scene->d_primT);
+        scene->d_rgb = scene->d_scratch = nullptr, scene->d_primId = nullptr, scene->d_primT = nullptr;
+        scene->fbPixels = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_rgb), px * perSequence * 12));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_scratch), px * perSequence * 12));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primId), px * perSequence * 4));
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primT), px * perSequence * 4));
+        scene->fbPixels = px * perSequence;
+    }
+    rt_stats total {};
+    for (int first = 0; first < nFrames; first += perSequence) {
+        const int n = std::min(perSequence, nFrames - first);
+        uint32_t fl = flags;
+        rt_stats st {};
+        int rc = RT_OK;
+        for (int attempt = 0; attempt < 5; attempt++) {
+            rc = rt_render_frames(scene, cameras + first, n, features, width, height, startDepth, nullptr, fl, scene->d_rgb, nullptr, nullptr, nullptr);
+            for (int f = 0; rc == RT_OK && features->enableBloomEffect && f < n; f++) // src/render.cpp:48-50
+                rc = rt_bloom(scene->d_rgb + 3 * px * f, scene->d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,
+                              features->bloomFilterIntensity, nullptr, nullptr);
+            if (rc == RT_OK) rc = rt_sync(scene, nullptr, &st);
+            if (rc == RT_ERR_AGAIN && attempt < 3) continue; // the task queues have grown: render the sequence again
+            if ((rc == RT_ERR_LIMIT || rc == RT_ERR_AGAIN) && !(fl & RT_RENDER_SERIAL)) { // beyond the default pipeline's limits: depth-first instead
+                fl |= RT_RENDER_SERIAL;
+                continue;
+            }
+            break;
+        }
+        if (rc != RT_OK) return rc;
+        for (int f = 0; f < n; f++) RT_HIP(hipMemcpy(rgb[first + f], scene->d_rgb + 3 * px * f, px * 12, hipMemcpyDeviceToHost));
+        total.primaryRays += st.primaryRays, total.shadowRays += st.shadowRays, total.secondaryRays += st.secondaryRays;
+        total.nodePairSteps += st.nodePairSteps, total.triangleTests += st.triangleTests, total.queryNodeSteps += st.queryNodeSteps;
+        total.pixels += st.pixels, total.stackOverflows += st.stackOverflows, total.referenceTreeQueries += st.referenceTreeQueries;
+        total.pipeline = st.pipeline;
+    }
+    if (stats) *stats = total;
+    return RT_OK;
+}
+
 int rt_selftest_division(uint32_t seed, uint64_t* mismatches, uint64_t* checked)
 {
     if (!mismatches || !checked) {

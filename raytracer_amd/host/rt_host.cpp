@@ -200,6 +200,27 @@ rt_stats renderImage(const Scene& scene, const BVHInterface& bvh, const Features
     check(rc, "rt_render_image");
     return stats;
 }
+rt_stats renderImages(const Scene& scene, const BVHInterface& bvh, const Features& features, std::span<const Trackball> cameras,
+                      std::span<Screen> screens, int startDepth, uint32_t flags)
+{
+    if (cameras.size() != screens.size() || cameras.empty()) throw std::invalid_argument("renderImages: one screen per camera, at least one");
+    const ivec2 res = screens[0].resolution();
+    std::vector<rt_camera> cams;
+    std::vector<float*> images;
+    for (size_t k = 0; k < cameras.size(); k++) {
+        if (screens[k].resolution().x != res.x || screens[k].resolution().y != res.y) throw std::invalid_argument("renderImages: screens of one resolution");
+        cams.push_back(cameras[k].deviceCamera());
+        images.push_back(&screens[k].pixels()[0].x);
+    }
+    const auto* own = dynamic_cast<const BVH*>(&bvh);
+    rt_scene* dev = own ? own->deviceScene() : createDeviceScene(bvh.nodes(), bvh.primitives(), nullptr, scene);
+    const rt_features f = toDevice(features);
+    rt_stats stats {};
+    const int rc = rt_render_images(dev, cams.data(), (int)cams.size(), &f, res.x, res.y, startDepth, flags, images.data(), &stats);
+    if (!own) rt_scene_destroy(dev);
+    check(rc, "rt_render_images");
+    return stats;
+}
 void renderImage(const Scene& scene, const BVHInterface& bvh, const Features& features, const Trackball& camera, Screen& screen)
 {
     (void)renderImage(scene, bvh, features, camera, screen, 0, 0);

@@ -196,6 +196,11 @@ void renderImage(const Scene& scene, const BVHInterface& bvh, const Features& fe
 rt_stats renderImage(const Scene& scene, const BVHInterface& bvh, const Features& features, const Trackball& camera, Screen& screen,
                      int startDepth, uint32_t flags = 0);
 
+// The loop that renders one frame per camera (src/main.cpp:515-526): screens[k] from cameras[k], all of one resolution.  The frames
+// are rendered several at a time by one launch sequence each (rt_render_images); every screen holds what renderImage writes for its camera.
+rt_stats renderImages(const Scene& scene, const BVHInterface& bvh, const Features& features, std::span<const Trackball> cameras,
+                      std::span<Screen> screens, int startDepth = 0, uint32_t flags = 0);
+
 rt_features toDevice(const Features& features);
 
 } // namespace rtamd

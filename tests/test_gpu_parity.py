@@ -446,6 +446,16 @@ def test_frames_rendered_together_equal_frames_rendered_alone():
             compare_frames(got, ro, f"{what}: frame {k} of {n} rendered together")
     with pytest.raises(api.RtError):
         g.render_frames_device(cams * 4, both_features()[0], W, H, 2, rgb.data_ptr(), stream=s0)  # 20 frames > RT_MAX_FRAMES
+    # rt_render_images: host images, any number of cameras (here 11: one sequence of eight frames and one of three), bloom included
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2, enableBloomEffect=1)
+    many = (cams * 3)[:11]
+    got = g.render_images(many, fg, W, H, start_depth=3)
+    rays = 0
+    for k, c in enumerate(many):
+        want = g.render_image(c, fg, W, H, start_depth=3, want_ids=False)
+        rays += want["stats"].rays
+        assert np.array_equal(got["rgb"][k].view(np.uint32), want["rgb"].view(np.uint32)), f"rt_render_images: frame {k}"
+    assert got["stats"].rays == rays
 
 
 def test_wavefront_matches_serial_and_is_reproducible():

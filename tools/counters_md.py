@@ -53,13 +53,13 @@ L, nL = by_kernel(l2, l2n, busy_l2)
 G, nG = by_kernel(gr, grn, busy_gr)
 allN = collections.Counter(sqn.values())
 lines = [f"# Counters of the headline frame's kernels ({what})", "",
-         "Three separate `rocprofv3 --pmc` passes over `tools/frame.py 2 dragon_glossy_bloom overlapped` (two frames of the headline configuration with the",
-         "launch sizes of overlapped frames, rendered one after the other), via `tools/pmc.sh`: `TCC_HIT_sum TCC_MISS_sum`; `SQ_WAVES SQ_INSTS_VALU",
+         "Three separate `rocprofv3 --pmc` passes over `tools/frame.py 16 dragon_glossy_bloom overlapped 1 8` (sixteen frames of the headline configuration",
+         "as two launch sequences of eight frames, with the launch sizes of overlapped sequences), via `tools/pmc.sh`: `TCC_HIT_sum TCC_MISS_sum`; `SQ_WAVES SQ_INSTS_VALU",
          "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY`; `GRBM_GUI_ACTIVE`.  Averages per dispatch over the dispatches",
          "that do work (launches that return at once are counted in the second column only).  L2 hit = HIT / (HIT + MISS); vector issue = 4 x",
          "SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); active lanes = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); waves per SIMD =",
          "4 x SQ_WAVE_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8); waiting = SQ_WAIT_ANY / SQ_WAVE_CYCLES.", "",
-         "| kernel | dispatches with work / all (2 frames) | L2 hit | vector issue | active lanes | waves/SIMD | waiting | VALU insts | GUI_ACTIVE |",
+         "| kernel | dispatches with work / all (2 sequences of 8 frames) | L2 hit | vector issue | active lanes | waves/SIMD | waiting | VALU insts | GUI_ACTIVE |",
          "|---|---|---|---|---|---|---|---|---|"]
 for k in sorted(A, key=lambda k: -A[k]["SQ_WAVE_CYCLES"]):
     n = nA[k]

@@ -1,4 +1,7 @@
-"""Render N frames of a bench workload (no counting pass, no timing) - a target for profilers."""
+"""Render N frames of a bench workload (no counting pass, no timing) - a target for profilers.
+
+usage: frame.py N [workload] [overlapped|alone] [streams] [frames per launch sequence]
+With frames per launch sequence K > 1 the N frames are rendered by rt_render_frames, K at a time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +19,16 @@ frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 flags = api.RT_RENDER_OVERLAPPED if (len(sys.argv) > 3 and sys.argv[3] == "overlapped") else 0  # launch sizes of frames that share the GPU
 inflight = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # frames queued at once, each on a stream of its own
-if inflight > 1:
+pooled = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+if pooled > 1:
+    streams = [torch.cuda.Stream() for _ in range(inflight)]
+    bufs = [torch.zeros((pooled, H, W, 3), dtype=torch.float32, device="cuda") for _ in range(inflight)]
+    for i, first in enumerate(range(0, n, pooled)):
+        k = i % inflight
+        scene.render_frames_device([cam] * min(pooled, n - first), feat, W, H, wl["start_depth"], bufs[k].data_ptr(), flags=flags,
+                                   stream=streams[k].cuda_stream)
+    stream = streams[0].cuda_stream
+elif inflight > 1:
     streams = [torch.cuda.Stream() for _ in range(inflight)]
     frames = [torch.zeros_like(frame) for _ in range(inflight)]
     for k in range(n):

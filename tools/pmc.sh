@@ -3,7 +3,7 @@
 tag=$1; ctrs=$2; shift; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/tools/frame.py 2 "$@" > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/tools/frame.py ${PMC_FRAMES:-2} "$@" > $out.log 2>&1 || { tail -5 $out.log; exit 1; }
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$out/**/p_counter_collection.csv",recursive=True)
