@@ -1701,7 +1701,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
-        + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(nMaterials * sizeof(GpuMaterial))
+        + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded((nTris / 32 + 1) * 4) + padded(nMaterials * sizeof(GpuMaterial))
         + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQNodes * sizeof(Node4)) + padded(nQPairs * sizeof(NodePair))
         + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert))
         + padded(nQuadNodes * sizeof(QuadNode)) + padded(nQuadLeaves * sizeof(QuadLeaf)) + 256;
@@ -1712,6 +1712,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     TriEdges* hEdges = carve<TriEdges>(hp, nTris);
     TriAttr* hAttr = carve<TriAttr>(hp, nTris);
     uint32_t* hBrute = carve<uint32_t>(hp, nTris);
+    uint32_t* hReflects = carve<uint32_t>(hp, nTris / 32 + 1);
     GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
     GpuLight* hLight = carve<GpuLight>(hp, nLights);
     GpuSphere* hSph = carve<GpuSphere>(hp, nSpheres);
@@ -1737,6 +1738,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         memcpy(hEdges, flat.triEdges.data(), nTris * sizeof(TriEdges));
         memcpy(hAttr, flat.triAttr.data(), nTris * sizeof(TriAttr));
         memcpy(hBrute, flat.bruteOrder.data(), nTris * 4);
+        for (size_t i = 0; i < nTris; i++) { // the material test of renderRay (src/recursive.cpp:62-80), once per triangle
+            const float* m = materials8 + 8 * (size_t)flat.triAttr[i].meshID;
+            if (m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f) hReflects[i >> 5] |= 1u << (i & 31);
+        }
     }
     for (uint32_t i = 0; i < nMaterials; i++) {
         const float* m = materials8 + 8 * (size_t)i;
@@ -1771,6 +1776,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.triEdges = carve<TriEdges>(dp, nTris);
     V.triAttr = carve<TriAttr>(dp, nTris);
     V.bruteOrder = carve<uint32_t>(dp, nTris);
+    V.triReflects = carve<uint32_t>(dp, nTris / 32 + 1);
     V.materials = carve<GpuMaterial>(dp, nMaterials);
     V.lights = carve<GpuLight>(dp, nLights);
     V.spheres = carve<GpuSphere>(dp, nSpheres);

@@ -131,6 +131,7 @@ struct SceneView {
     const TriEdges* triEdges;
     const TriAttr* triAttr;
     const uint32_t* bruteOrder; // compact triangle indices in primitives() array order
+    const uint32_t* triReflects; // one bit per compact triangle: its mesh's material has a non-zero ks (a hit there continues with a reflection)
     const GpuMaterial* materials;
     const GpuTexture* textures; // one per material
     const GpuLight* lights;

@@ -1040,17 +1040,22 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 // start, and it depends on which candidates hit a reflecting surface: that bit per candidate, all loads
                 // in flight together.
                 batchKids = L.nRays == 3 ? 2u : (L.nRays == 6 ? 3u : (L.nRays == 10 ? 4u : 5u)); // nRays = kids (kids + 1) / 2
-                uint32_t ctri[kMaxBatchRays], cmesh[kMaxBatchRays];
+                uint32_t ctri[kMaxBatchRays], cword[kMaxBatchRays];
 #pragma unroll
                 for (uint32_t c = 0; c < kMaxBatchRays; c++) ctri[c] = (c < L.nRays) ? P.hits[L.rayBase + c].tri : kNoHit;
+                // (triangles: the scene's bit per triangle, a table small enough to stay in the caches, instead of triangle -> mesh -> material)
 #pragma unroll
-                for (uint32_t c = 0; c < kMaxBatchRays; c++) cmesh[c] = (ctri[c] < kSphereBase) ? S.triAttr[ctri[c]].meshID : 0u;
+                for (uint32_t c = 0; c < kMaxBatchRays; c++) cword[c] = (ctri[c] < kSphereBase) ? S.triReflects[ctri[c] >> 5] : 0u;
 #pragma unroll
                 for (uint32_t c = 0; c < kMaxBatchRays; c++) {
                     if (ctri[c] == kNoHit) continue;
                     hitMask |= 1u << c;
-                    const float* mks = (ctri[c] < kSphereBase) ? S.materials[cmesh[c]].ks : S.spheres[ctri[c] - kSphereBase].ks;
-                    if ((mks[0] != 0.0f) || (mks[1] != 0.0f) || (mks[2] != 0.0f)) opensMask |= 1u << c;
+                    if (ctri[c] < kSphereBase) {
+                        opensMask |= ((cword[c] >> (ctri[c] & 31u)) & 1u) << c;
+                    } else {
+                        const float* mks = S.spheres[ctri[c] - kSphereBase].ks;
+                        if ((mks[0] != 0.0f) || (mks[1] != 0.0f) || (mks[2] != 0.0f)) opensMask |= 1u << c;
+                    }
                 }
                 if (!F.enableReflections) opensMask = 0;
                 // the candidate that stands for sample i lies one place further for every earlier sample with a loop of its own

@@ -6,7 +6,7 @@ root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/kt -o p -- python3 $root/tools/frame.py 3 "$@" > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/kt -o p -- python3 $root/tools/frame.py ${TIMELINE_FRAMES:-3} "$@" > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }
 python3 - $out <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/kt/**/p_kernel_trace.csv", recursive=True)[0]
