@@ -124,7 +124,7 @@ struct rt_scene {
     // Launch sequences over many pixels (several frames rendered together, or one very large frame): every round holds so many rays
     // that its fixed costs no longer count, and what pays is fewer rays - candidate batches of two children (three candidates for
     // two rays instead of ten for four, in twice the rounds) - and fewer rays handed over (a longer walk before a lane gives up).
-    uint32_t largeFromPixels = 6000000;   // RT_AMD_LARGE_FROM (pixels of the sequence's region; 0 = never)
+    uint32_t largeFromPixels = 4000000;   // RT_AMD_LARGE_FROM (pixels of the sequence's region; 0 = never)
     uint32_t batchWindowLarge = 2;        // RT_AMD_BATCH_WINDOW_LARGE
     uint32_t queryStepBudgetLarge = 32;   // RT_AMD_QBUDGET_LARGE
     bool quadTrace = false;          // group launches in a query tree run four lanes per ray (RT_AMD_QUAD_TRACE; default: 8 or 16)
@@ -2001,6 +2001,31 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
 
     // ---- wavefront pipeline ----
+    const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
+    const bool useQuery = groupOk && cull && !countRef && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
+        && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
+    // The path stage - the rays whose outcome the pixel's sampler depends on - runs as one persistent launch in which a group
+    // of lanes owns a pixel from its first ray to its last (path_kernel), or, without it, in frame-wide rounds.
+    const bool usePathGroup = scene->pathMode == 1 && groupOk && cull && !count && (scene->groupLanes == 8 || scene->groupLanes == 16)
+        && !features->enableTransparency; // the persistent schedules know no pass-through rays
+    // Rounds a full recursion tree needs when its loops are walked one child per round (batched loops need fewer): beyond what
+    // the round-based stage accepts, the pixel-per-lane launch takes the frame, whose chains may be as long as they like.
+    bool longChains = false;
+    {
+        const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? std::max(1u, features->numGlossySamples) : 1;
+        uint64_t links = 0, term = 1;
+        for (int l = startDepth; l <= RT_MAX_RAY_DEPTH && links < (1u << 24); l++) {
+            links += term, term *= fan;
+            if (!features->enableReflections) break;
+        }
+        const uint64_t ns = features->enableJitteredSampling ? (uint64_t)roundf(sqrtf((float)features->numPixelSamples)) : 0;
+        links *= std::max<uint64_t>(features->numPixelSamples, ns * ns);
+        longChains = links > kMaxRounds / 2;
+    }
+    const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count && !features->enableTransparency;
+    const bool usePath = usePathGroup || usePathLane;
+    if (usePath && nFrames > 1) return kNotPooled; // the persistent schedules take one frame at a time
+    // (buffers are sized only now: a sequence that is rendered frame by frame after all asks for one frame's worth)
     const size_t px = (size_t)width * height * (size_t)nFrames;
     if (px > w.accumPixels) {
         (void)hipFree(w.d_accum), (void)hipFree(w.d_nonfinite);
@@ -2027,30 +2052,6 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         RT_HIP(hipMalloc(&w.d_leafQ, wantLeaf * sizeof(LeafTask)));
         w.leafCap = (uint32_t)wantLeaf;
     }
-    const bool groupOk = features->enableAccelStructure && scene->groupLanes > 1 && (int)scene->treeDepth <= (scene->groupLanes == 4 ? GroupLayout<4>::kMaxTreeDepth : 30);
-    const bool useQuery = groupOk && cull && !countRef && scene->queryView.cert != nullptr && (scene->groupLanes == 8 || scene->groupLanes == 16)
-        && scene->queryDepth <= 48 && !(flags & RT_RENDER_REFERENCE_TREE);
-    // The path stage - the rays whose outcome the pixel's sampler depends on - runs as one persistent launch in which a group
-    // of lanes owns a pixel from its first ray to its last (path_kernel), or, without it, in frame-wide rounds.
-    const bool usePathGroup = scene->pathMode == 1 && groupOk && cull && !count && (scene->groupLanes == 8 || scene->groupLanes == 16)
-        && !features->enableTransparency; // the persistent schedules know no pass-through rays
-    // Rounds a full recursion tree needs when its loops are walked one child per round (batched loops need fewer): beyond what
-    // the round-based stage accepts, the pixel-per-lane launch takes the frame, whose chains may be as long as they like.
-    bool longChains = false;
-    {
-        const uint64_t fan = (features->enableReflections && features->enableGlossyReflection) ? std::max(1u, features->numGlossySamples) : 1;
-        uint64_t links = 0, term = 1;
-        for (int l = startDepth; l <= RT_MAX_RAY_DEPTH && links < (1u << 24); l++) {
-            links += term, term *= fan;
-            if (!features->enableReflections) break;
-        }
-        const uint64_t ns = features->enableJitteredSampling ? (uint64_t)roundf(sqrtf((float)features->numPixelSamples)) : 0;
-        links *= std::max<uint64_t>(features->numPixelSamples, ns * ns);
-        longChains = links > kMaxRounds / 2;
-    }
-    const bool usePathLane = (scene->pathMode == 2 || (longChains && scene->pathMode == 0)) && cull && !count && !features->enableTransparency;
-    const bool usePath = usePathGroup || usePathLane;
-    if (usePath && nFrames > 1) return kNotPooled; // the persistent schedules take one frame at a time
     // (rounds only) a glossy loop whose children are the last rays that can spawn anything is traced as one batch of candidates
     uint32_t batchRays = 0, batchWindow = 0;
     if (!usePath) {
