@@ -110,6 +110,9 @@ struct rt_scene {
                                     // RT_AMD_NO_BATCH: one child per round; at most 5)
     bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
     bool noShadowBound = false;     // RT_AMD_NO_SHADOW_BOUND: shadow rays are traced to their closest hit like every other ray
+    bool packets = true;            // the camera rays (the path stage's first round) are traced as packets of 64, one stack per wave
+                                    // (RT_AMD_PACKETS=0: one by one like every other stage)
+    uint32_t queryDepth4 = 0;       // depth of the query tree's 4-wide form
     uint32_t wideBelow = 32768;     // planned rounds expected to hold fewer rays run 16 lanes per ray (RT_AMD_WIDE_BELOW overrides, 0 = never)
     uint32_t laneModeAbove = 262144; // stages with at least this many rays run one ray per lane (RT_AMD_T1 overrides)
     uint32_t stepBudget = 96;        // ... and hand a ray over after this many steps (RT_AMD_BUDGET overrides, 0 = never)
@@ -1803,6 +1806,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         s->queryView.triPlane = dQPlane, s->queryView.triEdges = dQEdges, s->queryView.cert = dQCert;
         s->queryView.rootRef = qt.pairRootRef, s->queryView.nPairs = uint32_t(nQPairs); // root of the 4-wide form: node 0
         s->queryDepth = qt.pairDepth;
+        s->queryDepth4 = qt.maxDepth;
     }
     if (getenv("RT_AMD_VERBOSE"))
         fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s; "
@@ -1823,6 +1827,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_QBUDGET2_OVERLAPPED")) s->secondPassBudgetOverlapped = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_QBUDGET_OVERLAPPED")) s->queryStepBudgetOverlapped = (uint32_t)atoi(e);
     if (getenv("RT_AMD_NO_SHADOW_BOUND")) s->noShadowBound = true;
+    if (const char* e = getenv("RT_AMD_PACKETS")) s->packets = atoi(e) != 0;
     if (const char* e = getenv("RT_AMD_LARGE_FROM")) s->largeFromPixels = (uint32_t)atoll(e);
     if (const char* e = getenv("RT_AMD_BATCH_WINDOW_LARGE")) s->batchWindowLarge = (uint32_t)std::min(5, std::max(0, atoi(e)));
     if (const char* e = getenv("RT_AMD_QBUDGET_LARGE")) s->queryStepBudgetLarge = (uint32_t)atoi(e);
@@ -2228,6 +2233,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
                                                        : (laneModeAbove + groupRaysPerBlock - 1) / groupRaysPerBlock;
     const int reserve = (int)scene->treeDepth + 2; // stack room a group keeps free (see group_node_step)
     uint32_t gridNow = groupGrid; // workgroups of the next group launch: fewer where few rays are expected (the rest is fetched in chunks)
+    bool packetRound = false; // the stage being launched holds the camera rays in tile order and RT_AMD_PACKETS asks for packets
     bool anyHit = false; // the stage being launched holds shadow rays whose tag word is the shaded point's distance (see any_bound)
     auto launch_one = [&](uint32_t groupLanes, bool query) {
         T.fetch = w.d_roundCounts + nextFetch++;
@@ -2327,6 +2333,21 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         if (useQuery) w.fallSlots.push_back(nextFetch);
         uint32_t* fallCount = w.d_roundCounts + nextFetch++;
         T.fallCount = fallCount;
+        if (packetRound && useQuery && 3 * scene->queryDepth4 + 1 <= (uint32_t)kPacketStack) { // (a packet whose stack overflows all the same is traced again)
+            // camera rays, tile by tile: one walk per wave for 64 rays (packet_trace_kernel), whatever their number; what it
+            // cannot settle goes to the fall-back launch below like every query-tree launch's leftovers
+            T.S = scene->queryView;
+            T.fetch = w.d_roundCounts + nextFetch++;
+            if (count) hipLaunchKernelGGL(packet_trace_kernel<true>, dim3(traceGrid), dim3(kBlock), 0, st, T);
+            else hipLaunchKernelGGL(packet_trace_kernel<false>, dim3(traceGrid), dim3(kBlock), 0, st, T);
+            T.runLo = 0, T.runHi = 0xffffffffu;
+            T.indirect = w.d_fallList, T.indirectFrom = 0;
+            T.countPtr = fallCount, T.countSub = 0, T.countMaxItems = 0xffffffffu, T.countMul = 1;
+            gridNow = std::min(groupGrid, 256u);
+            launch_one(scene->groupLanes, false);
+            gridNow = groupGrid;
+            return;
+        }
         T.runLo = laneModeAbove;
         const uint32_t budget = (countRef || smallRound) ? 0u : (useQuery ? queryStepBudget : scene->stepBudget);
         T.stepBudget = budget, T.longCount = longCount;
@@ -2476,8 +2497,10 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         // a round counts as small when the plan's frame would have sent it to the group kernel (which is about as fast as the
         // other schedule up to half as many rays again, should this frame's round be larger)
         const bool smallRound = planned && scene->roundRays[r - 1] < laneModeAbove;
+        packetRound = r == 1 && scene->packets && features->numPixelSamples <= 1;
         launch_trace(w.d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? w.d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
                      smallRound ? scene->roundRays[r - 1] : 0u);
+        packetRound = false;
         P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);
         P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;

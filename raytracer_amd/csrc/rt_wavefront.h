@@ -570,6 +570,135 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
 }
 
 // ---------------------------------------------------------------------------------------------
+// packet_trace_kernel: the closest-hit query for rays that travel together - the camera rays of an 8 x 8 pixel tile share
+// their origin and nearly their direction, and the path stage's first ray list holds them tile by tile.  A wave takes 64
+// consecutive rays as one packet and walks the query tree ONCE for all of them: one stack per wave (node references only,
+// in LDS), every lane tests the popped node's four boxes - or the popped leaf's triangles - for its own ray, and a child is
+// pushed when any lane's ray enters it (the children in the order of the first such lane's entry distances, nearest on top).
+// The node is the same for all lanes, so its 112 bytes are fetched once per wave instead of once per lane, no lane waits
+// at a different place of the tree, and there is no per-lane stack.  A lane tests boxes and triangles its own ray would
+// have skipped; that only adds candidates: the result is the closest triangle of a superset of what the lane's own walk
+// tests, accepted under the same proof as every query-tree result (query_result_proven), else the ray goes to the list
+// of rays traced again in the caller's tree.  Packets are dealt to the waves by position (no work counter).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPacketStack = 96; // entries per wave: a walk needs at most three per level of the 4-wide tree and one
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void packet_trace_kernel(const TraceParams P)
+{
+    __shared__ uint32_t s_stack[(kBlock / 64) * kPacketStack];
+    uint32_t* const stack = s_stack + (threadIdx.x >> 6) * kPacketStack;
+    const SceneView& S = P.S;
+    const int lane = threadIdx.x & 63;
+    const uint32_t have = *P.countPtr;
+    const uint32_t items = have > P.countSub ? min(have - P.countSub, P.countMaxItems) : 0u;
+    const uint32_t total = items * P.countMul;
+    if (total < P.runLo || total >= P.runHi) return;
+    TraceCounters tc { 0, 0, 0 };
+    const uint32_t nPackets = (total + 63u) / 64u, gridWaves = gridDim.x * (kBlock / 64);
+    for (uint32_t packet = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); packet < nPackets; packet += gridWaves) {
+        const uint32_t idx = packet * 64u + (uint32_t)lane;
+        TraceLane T;
+        trace_lane_clear(T);
+        bool alive = false, unfit = false;
+        if (idx < total) {
+            const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
+            const float4 a = q[0], b = q[1];
+            alive = trace_begin<COUNT>(S, true, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
+            if (!alive) P.hits[idx] = HitRec { T.t, T.tri };
+            if (alive && !T.R.approx) unfit = true, alive = false; // the conservative tests need the approximate slabs
+        }
+        int sp = 0;
+        uint32_t cur = __ballot(alive) != 0ull ? S.rootRef : kTraversalDone; // the same on every lane
+        const bool counting = COUNT && alive && lane == __ffsll((long long)__ballot(alive)) - 1;
+        bool lost = false;
+        while (cur != kTraversalDone) {
+            if (cur & kLeafBit) {
+                if (alive) {
+                    const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
+                    TraceCounters one { 0, 0, 0 };
+                    leaf_test_narrow<COUNT, true>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, one, &T.tieT);
+                    if (COUNT && counting) tc.triTests += one.triTests; // (the wave fetches a leaf's triangles once: counted once)
+                }
+            } else {
+                if (COUNT && counting) tc.node4++; // (the wave fetches the node once: counted once)
+                Node4Hits h = node4_test(S.nodes4 + cur, T.R, T.t); // (every lane: the node is the wave's; a lane without a ray enters nothing)
+                uint32_t slots = 0; // the children this lane's ray enters
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!alive) h.key[k] = kMissKey;
+                    if (h.key[k] != kMissKey) slots |= 1u << (h.key[k] & 3u);
+                }
+                const unsigned long long entering = __ballot(slots != 0u);
+                if (entering != 0ull) {
+                    const int lead = __ffsll((long long)entering) - 1;
+                    uint32_t any = 0; // children some lane enters
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (__ballot((slots >> k) & 1u) != 0ull) any |= 1u << k;
+                    // the leader's children by its entry distances (the keys are sorted per lane), and the node's references
+                    const uint32_t lk0 = (uint32_t)__shfl((int)h.key[0], lead), lk1 = (uint32_t)__shfl((int)h.key[1], lead);
+                    const uint32_t lk2 = (uint32_t)__shfl((int)h.key[2], lead), lk3 = (uint32_t)__shfl((int)h.key[3], lead);
+                    const uint32_t r0 = (uint32_t)__shfl((int)h.ref[0], lead), r1 = (uint32_t)__shfl((int)h.ref[1], lead);
+                    const uint32_t r2 = (uint32_t)__shfl((int)h.ref[2], lead), r3 = (uint32_t)__shfl((int)h.ref[3], lead);
+#define RT_REF_OF(slot) ((slot) == 0u ? r0 : ((slot) == 1u ? r1 : ((slot) == 2u ? r2 : r3)))
+#define RT_PUSH(r)                                   \
+    do {                                             \
+        if (sp < kPacketStack) {                     \
+            if (lane == 0) stack[sp] = (r);          \
+        } else {                                     \
+            lost = true;                             \
+        }                                            \
+        sp++;                                        \
+    } while (0)
+                    uint32_t taken = 1u << (lk0 & 3u); // the leader enters at least one child
+                    if (lk1 != kMissKey) taken |= 1u << (lk1 & 3u);
+                    if (lk2 != kMissKey) taken |= 1u << (lk2 & 3u);
+                    if (lk3 != kMissKey) taken |= 1u << (lk3 & 3u);
+                    const uint32_t others = any & ~taken;
+                    // pushed first, popped last: the children only other lanes enter; then the leader's, farthest first
+                    if (others & 1u) RT_PUSH(r0);
+                    if (others & 2u) RT_PUSH(r1);
+                    if (others & 4u) RT_PUSH(r2);
+                    if (others & 8u) RT_PUSH(r3);
+                    if (lk3 != kMissKey) RT_PUSH(RT_REF_OF(lk3 & 3u));
+                    if (lk2 != kMissKey) RT_PUSH(RT_REF_OF(lk2 & 3u));
+                    if (lk1 != kMissKey) RT_PUSH(RT_REF_OF(lk1 & 3u));
+                    cur = RT_REF_OF(lk0 & 3u);
+#undef RT_PUSH
+#undef RT_REF_OF
+                    continue;
+                }
+            }
+            // next pending node of the packet
+            for (;;) {
+                if (sp == 0) {
+                    cur = kTraversalDone;
+                    break;
+                }
+                sp--;
+                if (sp >= kPacketStack) continue; // an entry that found no room (the packet's results are not used then)
+                __builtin_amdgcn_wave_barrier();
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)stack[sp]);
+                break;
+            }
+        }
+        bool unproven = false;
+        if (alive) {
+            unproven = !query_result_proven(S, T.R, T.t, T.tri, T.tieT, lost ? 1u : 0u);
+            for (uint32_t s_ = 0; s_ < S.nSpheres; s_++) // src/bvh.cpp:366-367
+                if (sphere_test(S.spheres[s_], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s_;
+            if (!unproven) P.hits[idx] = HitRec { T.t, T.tri };
+        }
+        const bool again = unfit || unproven;
+        if (__ballot(again) != 0ull) {
+            const uint32_t pos = wave_fetch(P.fallCount, again, lane);
+            if (again) P.fallList[pos] = idx;
+        }
+    }
+    if (COUNT) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Ray order for the big one-ray-per-lane launches.  A wave walks the tree fastest when its 64 rays walk the same nodes;
 // the deferred rays of a frame (last-level glossy rays, shadow rays) are produced in the order their pixels happened to
 // finish.  Three small kernels give a stage's rays a traversal order without moving them: a key per ray (origin cell and

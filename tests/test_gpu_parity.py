@@ -104,7 +104,8 @@ def test_work_counters_match_reference_traversal():
 def test_counting_the_frame_as_scheduled_changes_nothing(lane_mode_from, monkeypatch):
     """RT_RENDER_COUNT_SCHEDULE counts the traversal work of the default schedule (query tree, candidate batches) without
     changing the frame; the reference's rays are the same, the work differs from the reference walk's.  Small stages walk
-    node pairs with several lanes per ray; with one ray per lane from the first ray on, the 4-wide nodes are walked."""
+    node pairs with several lanes per ray (the camera rays go as packets through the 4-wide nodes); with one ray per lane from the
+    first ray on, the 4-wide nodes are walked."""
     if lane_mode_from:
         monkeypatch.setenv("RT_AMD_T1", str(lane_mode_from))
     sc = scenes.dragon_standin(n_u=120, n_v=24)
@@ -123,8 +124,8 @@ def test_counting_the_frame_as_scheduled_changes_nothing(lane_mode_from, monkeyp
     assert s1.triangleTests > 0 and s1.pipeline == api.RT_PIPELINE_ROUNDS
     if lane_mode_from:
         assert s1.queryNodeSteps > s1.rays
-    else:
-        assert s1.queryNodeSteps == 0 and s1.nodePairSteps > s1.rays
+    else:  # only the camera rays' packets walk 4-wide nodes, one fetch per wave and node
+        assert 0 < s1.queryNodeSteps < s1.rays and s1.nodePairSteps > s1.rays
 
 
 @pytest.mark.parametrize("depth", [0, 2, 6])
@@ -566,12 +567,14 @@ def test_unnested_caller_tree_is_walked_as_given():
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_LINK_BUDGET="3", RT_AMD_MIN_LANES="48"), dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="1"),
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="2", RT_AMD_ADVANCE_AT="4"), dict(RT_AMD_QUAD_TRACE="1"),
                                    dict(RT_AMD_NO_SHADOW_BOUND="1"), dict(RT_AMD_NO_SHADOW_BOUND="1", RT_AMD_T1="1", RT_AMD_QBUDGET="2"),
-                                   dict(RT_AMD_T1="1", RT_AMD_QBUDGET="1"), dict(RT_AMD_LARGE_FROM="1"), dict(RT_AMD_LARGE_FROM="1", RT_AMD_T1="1")])
+                                   dict(RT_AMD_T1="1", RT_AMD_QBUDGET="1"), dict(RT_AMD_LARGE_FROM="1"), dict(RT_AMD_LARGE_FROM="1", RT_AMD_T1="1"),
+                                   dict(RT_AMD_PACKETS="1"), dict(RT_AMD_PACKETS="0")])
 def test_tuning_knobs_change_nothing(knobs, monkeypatch):
     """Every schedule the tuning knobs select (one ray per lane with rays handed over after a few steps, other group
     widths, no candidate batches, another query tree, the path stage as one persistent launch per pixel group, lane or
     quad instead of frame-wide rounds, shadow rays traced to their closest hit instead of as bounded queries that stop at
-    the first occluder, the settings of large launch sequences) renders the frame of the default schedule bit for bit:
+    the first occluder, the settings of large launch sequences, camera rays traced as packets of 64 with one stack per wave or one by one)
+    renders the frame of the default schedule bit for bit:
     small scenes never reach the ray counts at which the default switches schedules by itself."""
     _, _, sc = scene_pair("knot")
     W, H = 320, 180
