@@ -36,7 +36,11 @@ struct Workspace {
     void* d_shadeQ = nullptr;
     void* d_leafQ = nullptr;
     uint32_t shadeCap = 0, leafCap = 0;
-    float* d_states = nullptr;      // path-state pool, one slot per pixel of the region
+    float* d_states = nullptr;      // path states, one slot per pixel of the region: headers alone (rounds) or whole records (persistent launches)
+    size_t stateWords = 0;          // ... its size in floats
+    float* d_frames = nullptr;      // rounds: pending glossy loops, by rayDepth then state (WaveParams::frameBase)
+    float* d_passes = nullptr;      // rounds with transparency: pending pass-through rays, by rayDepth then state
+    size_t frameStates = 0, passStates = 0; // states the two hold
     uint32_t* d_active[2] = { nullptr, nullptr };
     uint32_t* d_activeRay[2] = { nullptr, nullptr }; // first ray of each active state
     size_t pathRayCap = 0;
@@ -1579,7 +1583,7 @@ void free_workspace(Workspace* w)
 {
     if (!w) return;
     (void)hipFree(w->d_stats), (void)hipFree(w->d_work), (void)hipFree(w->d_cams), (void)hipFree(w->d_accum), (void)hipFree(w->d_nonfinite);
-    (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states);
+    (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states), (void)hipFree(w->d_frames), (void)hipFree(w->d_passes);
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
     (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_longList2), (void)hipFree(w->d_fallList);
@@ -2070,12 +2074,32 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         }
     }
     const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
+    // path states: the rounds keep 64-byte headers here and the loop frames / pass records in arrays of their own; a persistent
+    // launch keeps a state's header, frames and pass records together (kStateDwords)
+    const uint32_t stateStride = usePath ? (uint32_t)kStateDwords : 16u;
+    if (w.stateWords < (size_t)nWork * stateStride) {
+        (void)hipFree(w.d_states);
+        w.d_states = nullptr, w.stateWords = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_states), (size_t)nWork * stateStride * sizeof(float)));
+        w.stateWords = (size_t)nWork * stateStride;
+    }
+    if (!usePath && w.frameStates < nWork) {
+        (void)hipFree(w.d_frames);
+        w.d_frames = nullptr, w.frameStates = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_frames), (size_t)nWork * RT_MAX_RAY_DEPTH * kFrameDwords * sizeof(float)));
+        w.frameStates = nWork;
+    }
+    if (!usePath && features->enableTransparency && w.passStates < nWork) {
+        (void)hipFree(w.d_passes);
+        w.d_passes = nullptr, w.passStates = 0;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_passes), (size_t)nWork * RT_MAX_RAY_DEPTH * kPassDwords * sizeof(float)));
+        w.passStates = nWork;
+    }
     if (w.stateCap < nWork) {
-        (void)hipFree(w.d_states), (void)hipFree(w.d_active[0]), (void)hipFree(w.d_active[1]);
+        (void)hipFree(w.d_active[0]), (void)hipFree(w.d_active[1]);
         (void)hipFree(w.d_activeRay[0]), (void)hipFree(w.d_activeRay[1]);
-        w.d_states = nullptr, w.d_active[0] = w.d_active[1] = nullptr, w.stateCap = 0;
+        w.d_active[0] = w.d_active[1] = nullptr, w.stateCap = 0;
         w.d_activeRay[0] = w.d_activeRay[1] = nullptr;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_states), (size_t)nWork * kStateDwords * sizeof(float)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_active[0]), (size_t)nWork * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_active[1]), (size_t)nWork * sizeof(uint32_t)));
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_activeRay[0]), (size_t)nWork * sizeof(uint32_t)));
@@ -2195,7 +2219,8 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     P.qCount = w.d_work + 8;
     P.shadeCap = w.shadeCap, P.leafCap = w.leafCap;
     P.lightDraws = lightDraws;
-    P.states = w.d_states;
+    P.states = w.d_states, P.stateStride = stateStride;
+    P.frameBase = w.d_frames, P.passBase = features->enableTransparency ? w.d_passes : nullptr, P.stateCap = nWork;
     P.pathRays = static_cast<RayRec*>(w.d_pathRays[0]), P.pathRaysIn = nullptr;
     P.rayCap = (uint32_t)(w.pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : w.pathRayCap);
     P.batchRays = batchRays, P.batchWindow = batchWindow;

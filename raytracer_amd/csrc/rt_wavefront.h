@@ -81,7 +81,16 @@ struct WaveParams {
     uint32_t* qCount;        // [0] shade tasks appended, [1] leaf tasks appended (both keep counting past capacity),
                              // [2] path states allocated
     uint32_t shadeCap, leafCap;
-    float* states;           // PathState pool: kStateDwords floats per state
+    float* states;           // path states: a 64-byte header per state, stateStride floats apart
+    uint32_t stateStride;    // 16 in the rounds (headers packed; loop frames and pass records in arrays of their own, below);
+                             // kStateDwords where a persistent launch keeps header, frames and pass records of a state together
+    // rounds: the pending glossy loop of rayDepth l of state s is frameBase + (l * stateCap + s) * kFrameDwords (all states'
+    // frames of one depth lie together: the states of a round mostly sit at the same depth, and neighbours in the active list
+    // are neighbours in memory), its pending pass-through ray passBase + (l * stateCap + s) * kPassDwords (null without
+    // transparency: nothing is allocated for them)
+    float* frameBase;
+    float* passBase;
+    uint32_t stateCap;
     const uint32_t* activeIn; // state indices whose rays were traced this round
     uint32_t* activeOut;      // survivors
     const uint32_t* activeInCount;
@@ -995,9 +1004,12 @@ constexpr uint32_t kHolePixel = 0xffffffffu; // a reserved but unused ShadeTask 
 // frames: this lane's frame storage in HBM (null while the lane has none: lanes allocate lazily).
 // TRANSP: the frame has transparency enabled (pass-through rays exist); compiled apart so that frames without it do not carry its registers
 template <bool TRANSP, typename AllocFn>
-__device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, float*& frames, AllocFn&& allocFrames, const int lane,
-                                              uint32_t& cPrimary, uint32_t& cSecondary, uint32_t& cDrop, uint32_t* s_n, uint32_t* s_base)
+__device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, float*& frames, float* const passes, AllocFn&& allocFrames,
+                                              const int lane, uint32_t& cPrimary, uint32_t& cSecondary, uint32_t& cDrop, uint32_t* s_n,
+                                              uint32_t* s_base)
 {
+    // frames / passes: this lane's record of rayDepth 0; the record of rayDepth l lies l * levelStride further
+    const size_t frameLevel = (size_t)P.stateCap * kFrameDwords, passLevel = (size_t)P.stateCap * kPassDwords;
     const SceneView& S = P.S;
     const rt_features& F = P.F;
     const bool deferLeaves = (P.lightDraws == 0);
@@ -1088,7 +1100,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 break;
             }
             case PS_GLOSSY: {
-                float4* fq = reinterpret_cast<float4*>(frames + L.loopDepth * kFrameDwords);
+                float4* fq = reinterpret_cast<float4*>(frames + L.loopDepth * frameLevel);
                 const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3], f4 = fq[4];
                 const vec3 fW = make3(f0.x, f0.y, f0.z), rorg = make3(f0.w, f1.x, f1.y), rdir = make3(f1.z, f1.w, f2.x);
                 const vec3 nrm = make3(f2.y, f2.z, f2.w), ks = make3(f3.x, f3.y, f3.z);
@@ -1133,9 +1145,9 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     L.state = PS_TRACE;
                     break;
                 }
-                frames[L.loopDepth * kFrameDwords + 16] = __uint_as_float(i);
+                frames[L.loopDepth * frameLevel + 16] = __uint_as_float(i);
                 if (!launched) { // loop finished: the hit's pass-through ray if one waits, else resume the enclosing loop
-                    const float* pr = frames + kPassOff + L.loopDepth * kPassDwords;
+                    const float* pr = passes + L.loopDepth * passLevel;
                     L.state = PS_POP;
                     if ((TRANSP && F.enableTransparency) && pr[9] != 0.0f) {
                         const float4* pq = reinterpret_cast<const float4*>(pr);
@@ -1223,7 +1235,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             if (__ballot(pushFrame && frames == nullptr) != 0ull) allocFrames(pushFrame && frames == nullptr);
             if (pushFrame) {
                 const int level = openLoop ? L.depth : L.depth - 1; // rayDepth of the hit (a specular chain has already moved on)
-                float4* fq = reinterpret_cast<float4*>(frames + level * kFrameDwords);
+                float4* fq = reinterpret_cast<float4*>(frames + level * frameLevel);
                 if (openLoop) {
                     const Mat m = load_material(S, st.matInfo & 0x7fffffffu, (st.matInfo >> 31) != 0);
                     fq[0] = make_float4(L.curW.x, L.curW.y, L.curW.z, L.to.x);
@@ -1236,7 +1248,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     fq[4] = make_float4(__uint_as_float(0xffffffffu), __uint_as_float((uint32_t)(L.loopDepth + 1)), 0.0f, 0.0f);
                 }
                 if ((TRANSP && F.enableTransparency)) {
-                    float4* pq = reinterpret_cast<float4*>(frames + kPassOff + level * kPassDwords);
+                    float4* pq = reinterpret_cast<float4*>(passes + level * passLevel);
                     // generatePassthroughRay (src/recursive.cpp:112-123): from just past the hit point, same direction
                     const vec3 d = make3(st.dx, st.dy, st.dz);
                     const vec3 porg = make3(st.px, st.py, st.pz) + 0.00001f * d;
@@ -1268,7 +1280,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     cDrop++;
                     L.state = PS_DONE;
                 } else {
-                    const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * kFrameDwords);
+                    const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * frameLevel);
                     const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
                     const vec3 rorg = make3(f0.w, f1.x, f1.y), rdir = make3(f1.z, f1.w, f2.x), nrm = make3(f2.y, f2.z, f2.w);
                     const float radius = f3.w;
@@ -1299,7 +1311,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             const uint32_t N = F.numGlossySamples;
             const uint32_t shadeBase = shadeSlot, leafBase = leafSlot;
             if (wantConsume) {
-                const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * kFrameDwords);
+                const float4* fq = reinterpret_cast<const float4*>(frames + L.loopDepth * frameLevel);
                 const float4 f0 = fq[0], f3 = fq[3], f4 = fq[4];
                 const vec3 fW = make3(f0.x, f0.y, f0.z), ks = make3(f3.x, f3.y, f3.z);
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
@@ -1346,7 +1358,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 }
                 L.nRays = 1;
                 const uint32_t nextChild = __float_as_uint(f4.x) + batchKids;
-                frames[L.loopDepth * kFrameDwords + 16] = __uint_as_float(nextChild);
+                frames[L.loopDepth * frameLevel + 16] = __uint_as_float(nextChild);
                 if (nextChild < N) { // the loop's remaining children: another batch, or a last single child as an ordinary ray
                     L.state = PS_GLOSSY;
                 } else {
@@ -1452,7 +1464,7 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
             L.rayBase = pos[k];
             if (pos[k] < P.rayCap) store_ray(P.pathRays + pos[k], L.to, L.td, FLT_MAX, 0u);
             else cDrop++;
-            store_header(P.states + (size_t)pos[k] * kStateDwords, L);
+            store_header(P.states + (size_t)pos[k] * P.stateStride, L);
             P.activeOut[pos[k]] = pos[k];
             P.activeRayOut[pos[k]] = pos[k];
         }
@@ -1475,12 +1487,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         L.state = PS_DONE;
         L.nRays = 1, L.rayBase = 0;
         float* frames = nullptr;
+        float* passes = nullptr;
         uint32_t slot = 0;
         if (i < total) {
             slot = P.activeIn[i];
-            float* s = P.states + (size_t)slot * kStateDwords;
-            load_header(s, L);
-            frames = s + 16;
+            load_header(P.states + (size_t)slot * P.stateStride, L);
+            frames = P.frameBase + (size_t)slot * kFrameDwords;
+            if (TRANSP) passes = P.passBase + (size_t)slot * kPassDwords;
             L.rayBase = P.activeRayIn[i];
             if (L.nRays > 1) {
                 L.state = PS_BATCH;
@@ -1492,7 +1505,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
             }
         }
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
-        advance_lanes<TRANSP>(P, L, frames, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
+        advance_lanes<TRANSP>(P, L, frames, passes, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
         const bool active = (L.state == PS_TRACE);
         const bool single = active && L.nRays <= 1; // a batch reserved its rays when it was emitted
         uint32_t pos, rpos;
@@ -1504,7 +1517,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
             else cDrop++;
         }
         if (active) {
-            store_header(P.states + (size_t)slot * kStateDwords, L);
+            store_header(P.states + (size_t)slot * P.stateStride, L);
             P.activeOut[pos] = slot;
             P.activeRayOut[pos] = L.rayBase;
         }
