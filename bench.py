@@ -197,7 +197,12 @@ def main():
         t1 = time.perf_counter()
         scene.render_device(cam, feat, W, H, wl["start_depth"], probe.data_ptr(), region=region, flags=flags, stream=0)
         torch.cuda.synchronize()
-        if (time.perf_counter() - t1) * 1e3 < 3.0:
+        probe_ms = torch.tensor([(time.perf_counter() - t1) * 1e3], dtype=torch.float64)
+        if world > 1:  # every rank must cut the steps into the same sequences (their exchanges pair up): the slowest rank's time decides
+            if args.backend == "nccl":
+                probe_ms = probe_ms.to(dev)
+            dist.all_reduce(probe_ms, op=dist.ReduceOp.MAX)
+        if float(probe_ms.item()) < 3.0:
             K = 2
         del probe
     K = max(1, min(K, (8 * 1920 * 1080 * world) // (W * H)))  # ... within 16.6 M pixels per rank (about 3 KB of queues and path states per pixel)
