@@ -270,6 +270,12 @@ def main():
                 if e.code != api.RT_ERR_AGAIN:
                     raise
                 again = True
+        if world > 1:  # a rank whose queues have grown renders its set-up sequences again: all ranks go along (the exchanges pair up)
+            flag = torch.tensor([1.0 if again else 0.0], dtype=torch.float64)
+            if args.backend == "nccl":
+                flag = flag.to(dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            again = bool(flag.item() > 0)
         if not again:
             break
     for i, (first, count) in enumerate(sequences(args.warmup)):
