@@ -52,11 +52,25 @@ for spec in sys.argv[1:]:
                 print("  (set-up pass %d: %s)" % (rep, e))
     rays = (stats.primaryRays + stats.shadowRays + stats.secondaryRays) / K
     n = max(2 * S, 24 // K)
+    n *= int(os.environ.get("RT_PROBE_LONG", "1"))
+    extra = 0
     t0 = time.perf_counter()
+    if os.environ.get("RT_PROBE_STAGGER"):  # put the streams out of step: stream k first renders a shorter sequence (counted):
+        # RT_PROBE_STAGGER = its frames per stream, comma separated (1 = k + 1 frames on stream k)
+        spec = os.environ["RT_PROBE_STAGGER"]
+        first = [int(x) for x in spec.split(",")] if "," in spec else [k + 1 for k in range(S)]
+        for k in range(S):
+            m = min(K, first[k % len(first)])
+            if m <= 0:
+                continue
+            extra += m
+            with torch.cuda.stream(streams[k]):
+                scene.render_frames_device([cam] * m, feat, W, H, wl["start_depth"], frames[k].data_ptr(), region=reg, flags=fl,
+                                           stream=streams[k].cuda_stream)
     for i in range(n):
         batch(i)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / (n * K)
+    dt = (time.perf_counter() - t0) / (n * K + extra)
     print("%2d frames per sequence on %d stream(s)%s, world %d: %.3f ms per frame, %.0f Mrays/s per GPU" % (K, S, " (overlapped sizes)" if fl else "", world, dt * 1e3, rays / dt / 1e6), flush=True)
     del streams, frames, scratch, host, scene
     torch.cuda.empty_cache()
