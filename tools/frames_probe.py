@@ -1,7 +1,12 @@
 """Throughput of the headline frame rendered K frames per launch sequence (rt_render_frames) on S streams.
 
 usage: python tools/frames_probe.py K:S[:flags] ...   e.g. 1:4 4:1 4:2 8:2   (flags: o = RT_RENDER_OVERLAPPED)
-A step is one frame: render + bloom + copy to pinned host memory, as in bench.py.
+A step is one frame: render + bloom + copy to pinned host memory, as in bench.py.  Environment:
+  RT_PROBE_WORLD=N       rank 0's stripes of a world of N (no exchange)      RT_PROBE_WORKLOAD=<bench workload>
+  RT_PROBE_NO_COPY / RT_PROBE_NO_BLOOM / RT_PROBE_NO_SHADOWS   leave that part out
+  RT_PROBE_LONG=m        m times as many sequences                            RT_PROBE_HW_QUEUES=q (default 8)
+  RT_PROBE_STAGGER=a,b,c,d  stream k first renders a sequence of that many frames (1 = k + 1): the streams run out of step
+Every configuration gets a scene of its own (a scene keeps one buffer set per stream).
 """
 import os, sys, time
 os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_PROBE_HW_QUEUES", "8")
