@@ -97,19 +97,20 @@ enum {
                                   per ray or in the caller's tree (nodePairSteps), triangle tests, including candidate
                                   rays that are later discarded and rays traced a second time.  RT_RENDER_COUNT_WORK
                                   counts the reference's own walk instead and wins when both are set. */
-    RT_RENDER_OVERLAPPED = 16, /* flag: the caller keeps several frames queued on different streams (frames are independent:
-                                  main.cpp renders one per camera, src/main.cpp:515-526).  A scene holds one set of frame
-                                  buffers per stream (up to four), so such frames overlap on the GPU; with this flag
-                                  the launches of a frame are sized for the throughput of the overlapped frames rather
-                                  than for the latency of a frame that has the GPU to itself.  Frames are identical
-                                  either way. */
+    RT_RENDER_OVERLAPPED = 16, /* flag: the caller keeps several frames or launch sequences (rt_render_frames) queued on
+                                  different streams (frames are independent: main.cpp renders one per camera,
+                                  src/main.cpp:515-526).  A scene holds one set of working buffers per stream (up to eight),
+                                  so they overlap on the GPU; with this flag the launches are sized for the throughput of
+                                  the overlapped work rather than for the latency of a frame that has the GPU to itself.
+                                  Frames are identical either way. */
     RT_RENDER_SERIAL = 4       /* flag: evaluate each pixel as one depth-first recursion and sum radiance in the
                                   reference's nested float order (src/recursive.cpp:25-83); the default pipeline
-                                  defers shadow rays and last-level rays and sums per pixel in fixed point.
-                                  Implied by enableTransparency (pass-through rays, src/recursive.cpp:112-123,155-163,
-                                  and light through transparent occluders, src/light.cpp:107-136, whose walk - endless
-                                  in the reference when the shaded surface is met more than 1e-5 off - stops after
-                                  64 surfaces) */
+                                  defers shadow rays and last-level rays and sums per pixel in fixed point.  Taken by
+                                  itself only for frames beyond the default pipeline's limits (enableTransparency with a
+                                  recursion tree of more than 4095 sequential rays per pixel).  With enableTransparency
+                                  either pipeline follows a light sample through transparent occluders
+                                  (src/light.cpp:107-136) for at most 64 surfaces: the reference's walk never ends
+                                  when the shaded surface is met more than 1e-5 off */
 };
 
 typedef struct rt_bvh rt_bvh;     /* host-side BVH in the reference's node / primitive layout */
