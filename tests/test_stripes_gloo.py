@@ -89,7 +89,8 @@ def test_stripe_gather_over_gloo(tmp_path, world, H, W):
     assert out.read_text() == "1"
 
 
-@pytest.mark.parametrize("world,H,W,K", [(2, 64, 40, 4), (2, 72, 33, 3), (3, 40, 16, 5), (3, 40, 16, 2)])
+@pytest.mark.parametrize("world,H,W,K", [(2, 64, 40, 4), (2, 72, 33, 3), (3, 40, 16, 5), (3, 40, 16, 2),
+                                         (8, 1080, 4, 10), (4, 1080, 4, 5)])  # the headline frame's 135 stripes over 8 and 4 ranks
 def test_sequence_of_frames_assembled_on_their_root_ranks(tmp_path, world, H, W, K):
     out = tmp_path / "ok.txt"
     mp.spawn(assemble_worker, args=(world, free_port(), H, W, K, str(out)), nprocs=world, join=True)
