@@ -447,6 +447,16 @@ def test_frames_rendered_together_equal_frames_rendered_alone():
             compare_frames(got, ro, f"{what}: frame {k} of {n} rendered together")
     with pytest.raises(api.RtError):
         g.render_frames_device(cams * 4, both_features()[0], W, H, 2, rgb.data_ptr(), stream=s0)  # 20 frames > RT_MAX_FRAMES
+    # frames whose size is no multiple of the 8 x 8 pixel tile: every frame of the sequence ends in partial tiles
+    Wo, Ho = 322, 181
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2)
+    odd = [api.camera_from_trackball(Wo, Ho, dist=2.0 + 0.4 * k, rot_deg=(20.0, 15.0 + 80.0 * k, 0.0)) for k in range(3)]
+    seq = torch.full((3, Ho, Wo, 3), -1.0, dtype=torch.float32, device="cuda")
+    g.render_frames_device(odd, fg, Wo, Ho, 3, seq.data_ptr(), stream=s0)
+    g.sync(s0)
+    for k, c in enumerate(odd):
+        want = g.render_image(c, fg, Wo, Ho, start_depth=3, want_ids=False)
+        assert np.array_equal(seq[k].cpu().numpy().view(np.uint32), want["rgb"].view(np.uint32)), f"{Wo}x{Ho}: frame {k}"
     # rt_render_images: host images, any number of cameras (here 11: one sequence of eight frames and one of three), bloom included
     fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=2, enableBloomEffect=1)
     many = (cams * 3)[:11]
