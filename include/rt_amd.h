@@ -126,6 +126,13 @@ const char* rt_last_error(void);
  * triangles as BVHInterface::Primitive records (100 bytes: meshID, 3 x {position, normal, texCoord};
  * src/bvh_interface.h:14-23) in gather order (mesh order, then triangle order; src/bvh.cpp:63-74). */
 int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out);
+/* The same constructor with features.extra.enableBvhSahBinning (src/bvh.cpp:472-495): spans are split by
+ * splitPrimitivesBySAHBin (src/extra.cpp:582-699: sorted along the longest axis, up to 50 bins over the centroid
+ * interval, the cheapest split after a bin) and a span whose cheapest split is no cheaper than testing all of
+ * its triangles becomes a leaf of that many triangles.  RT_ERR_INVALID for input the reference's code is
+ * undefined on: more than four triangles with one centroid coordinate on their split axis (the bin index is
+ * 0/0 converted to size_t).  rt_scene_create accepts leaves of up to 63 triangles and trees of up to 32 levels. */
+int rt_bvh_build_sah_binning(const void* prims, uint32_t nPrims, rt_bvh** out);
 void rt_bvh_destroy(rt_bvh* bvh);
 /* BVHInterface::nodes() / primitives() / numLevels() / numLeaves() (src/bvh_interface.h:64-71).
  * Nodes are 32 bytes (src/bvh_interface.h:28-54), index 1 is the reference's unused dummy; primitives

@@ -141,6 +141,8 @@ struct orc_scene {
     std::vector<Node> nodes;
     std::vector<StoredPrim> prims;
     uint32_t numLevels = 0, numLeaves = 0;
+    bool sahBinning = false;     // features.extra.enableBvhSahBinning (src/common.h:63)
+    bool buildUndefined = false; // the SAH build met a span for which the reference's bin index is undefined
 };
 
 namespace {
@@ -188,10 +190,83 @@ size_t splitPrimitivesByMedian(uint32_t axis, StoredPrim* p, size_t n) // src/bv
         std::sort(p, p + n, [](const StoredPrim& a, const StoredPrim& b) { return computePrimitiveCentroid(a.p).z < computePrimitiveCentroid(b.p).z; });
     return (n + 1) / 2;
 }
+// Bin of primitive i of a span sorted along `axis` (src/extra.cpp:582-607).  The reference converts the float
+// quotient to size_t; for a span whose centroids coincide on the axis that quotient is 0/0 and the conversion
+// is undefined: reported through `undefined`.
+size_t determineBucketIndex(size_t i, size_t nBins, uint32_t axis, const StoredPrim* p, size_t n, bool& undefined)
+{
+    const V3 sub = computePrimitiveCentroid(p[i].p) - computePrimitiveCentroid(p[0].p);
+    const V3 len = computePrimitiveCentroid(p[n - 1].p) - computePrimitiveCentroid(p[0].p);
+    float q;
+    if (axis == 0) q = float(nBins) * sub.x / len.x;
+    else if (axis == 1) q = float(nBins) * sub.y / len.y;
+    else q = float(nBins) * sub.z / len.z;
+    if (!(q >= 0.0f && q < 1.0e9f)) {
+        undefined = true;
+        return 0;
+    }
+    size_t idx = size_t(q);
+    if (idx == nBins) idx--;
+    return idx;
+}
+float calculateAABBSurfaceArea(const AABB& b) // src/extra.cpp:609-613
+{
+    const V3 d = b.upper - b.lower;
+    const V3 axes { std::fabs(d.x), std::fabs(d.y), std::fabs(d.z) };
+    return 2 * (axes.x * axes.y + axes.x * axes.z + axes.y * axes.z);
+}
+constexpr size_t kNoSplit = size_t(-1);
+// src/extra.cpp:623-699: sort along the axis, 50 bins (fewer for spans of fewer primitives) over the centroid
+// interval, the cheapest of the splits after each bin by traversal cost 1.5 + (area x count of either side) /
+// area of the span's box; no split when that is not below the count.
+size_t splitPrimitivesBySAHBin(const AABB& aabb, uint32_t axis, StoredPrim* p, size_t N, bool& undefined)
+{
+    size_t nBins = 50;
+    if (N < nBins) nBins = N;
+    splitPrimitivesByMedian(axis, p, N);
+    std::vector<size_t> binSize(nBins, 0), binStart(nBins, 0);
+    for (size_t i = 0; i < N; i++) {
+        const size_t b = determineBucketIndex(i, nBins, axis, p, N, undefined);
+        if (undefined || b >= nBins) {
+            undefined = true;
+            return kNoSplit;
+        }
+        binSize[b]++;
+    }
+    size_t relStart = 0;
+    for (size_t i = 0; i < nBins; i++) {
+        binStart[i] = relStart;
+        relStart += binSize[i];
+    }
+    const float outerSurfaceArea = calculateAABBSurfaceArea(aabb);
+    float minCost = std::numeric_limits<float>::max();
+    size_t minIndex = kNoSplit;
+    const float baseCost = float(N);
+    const float travCost = 1.5f;
+    for (size_t i = 0; i < nBins - 1; i++) {
+        const size_t leftSize = binStart[i + 1];
+        const float leftSurfaceArea = calculateAABBSurfaceArea(computeSpanAABB(p, leftSize));
+        const size_t rightSize = N - leftSize;
+        const float rightSurfaceArea = calculateAABBSurfaceArea(computeSpanAABB(p + leftSize, rightSize));
+        const float cost = travCost + (leftSurfaceArea * float(leftSize) + rightSurfaceArea * float(rightSize)) / outerSurfaceArea;
+        if (cost < minCost) {
+            minCost = cost;
+            minIndex = leftSize;
+        }
+    }
+    if (minCost >= baseCost) return kNoSplit;
+    return minIndex;
+}
 void buildRecursive(orc_scene& s, StoredPrim* p, size_t n, uint32_t nodeIndex) // src/bvh.cpp:429-512
 {
     const AABB aabb = computeSpanAABB(p, n);
-    if (n <= 4) { // BVH::LeafSize, src/bvh.h:49
+    size_t split = 0;
+    bool leaf = n <= 4; // BVH::LeafSize, src/bvh.h:49
+    if (!leaf && s.sahBinning) { // src/bvh.cpp:472-495: a span the heuristic does not split becomes a leaf of any size
+        split = splitPrimitivesBySAHBin(aabb, computeAABBLongestAxis(aabb), p, n, s.buildUndefined);
+        leaf = split == kNoSplit;
+    }
+    if (leaf) {
         // buildLeafData appends the primitives and THEN records the offset (src/bvh.cpp:387-392) ...
         s.prims.insert(s.prims.end(), p, p + n);
         Node leaf;
@@ -202,7 +277,7 @@ void buildRecursive(orc_scene& s, StoredPrim* p, size_t n, uint32_t nodeIndex) /
         // ... and buildRecursive appends them a second time (src/bvh.cpp:458): the offset points at this copy.
         s.prims.insert(s.prims.end(), p, p + n);
     } else {
-        size_t split = splitPrimitivesByMedian(computeAABBLongestAxis(aabb), p, n);
+        if (!s.sahBinning) split = splitPrimitivesByMedian(computeAABBLongestAxis(aabb), p, n);
         const uint32_t left = uint32_t(s.nodes.size());
         s.nodes.emplace_back();
         const uint32_t right = uint32_t(s.nodes.size());
@@ -919,6 +994,13 @@ orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const floa
     return s;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
+int orc_scene_rebuild_bvh(orc_scene* s, int sahBinning)
+{
+    s->sahBinning = sahBinning != 0;
+    s->buildUndefined = false;
+    buildBVH(*s);
+    return s->buildUndefined ? 1 : 0;
+}
 void orc_set_shadow_walk_cap(int surfaces) { g_shadowWalkCap = surfaces; }
 int orc_scene_set_texture(orc_scene* s, uint32_t material, const float* rgb, int width, int height)
 {

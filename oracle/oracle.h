@@ -59,6 +59,11 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const uint32_t* prims25, uint32_t nPrims, const float* materials9, uint32_t nMaterials,
                             const float* lights22, uint32_t nLights, const float* spheres12, uint32_t nSpheres);
 void orc_scene_destroy(orc_scene* s);
+/* Builds the scene's BVH again: median splits (sahBinning = 0, what orc_scene_create does; src/bvh.cpp:499) or
+ * features.extra.enableBvhSahBinning (src/bvh.cpp:472-495, src/extra.cpp:582-699).  Returns 1 when the SAH build
+ * met a span whose centroids coincide on the split axis: the reference's bin index is 0/0 converted to size_t
+ * there, which is undefined. */
+int orc_scene_rebuild_bvh(orc_scene* s, int sahBinning);
 /* Test aid, not reference behaviour: stop the walk through transparent occluders (src/light.cpp:107-136) after this many
    surfaces (0 = never, as the reference). */
 void orc_set_shadow_walk_cap(int surfaces);

@@ -96,6 +96,7 @@ def lib():
     vp = C.c_void_p
     L.rt_last_error.restype = C.c_char_p
     L.rt_bvh_build.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.rt_bvh_build_sah_binning.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.rt_bvh_destroy.argtypes = [vp]
     for n in ("rt_bvh_num_nodes", "rt_bvh_num_primitives", "rt_bvh_num_levels", "rt_bvh_num_leaves"):
         getattr(L, n).restype = C.c_uint32
@@ -147,12 +148,13 @@ def camera_from_trackball(width, height, fov_deg=50.0, dist=3.0, look_at=(0.0, 0
 
 
 class Bvh:
-    """Host BVH in the reference's nodes()/primitives() layout (rt_bvh_build)."""
+    """Host BVH in the reference's nodes()/primitives() layout (rt_bvh_build; rt_bvh_build_sah_binning with sah_binning)."""
 
-    def __init__(self, prims25):
+    def __init__(self, prims25, sah_binning=False):
         self.input = np.ascontiguousarray(prims25, np.uint32).reshape(-1, 25)
         h = C.c_void_p()
-        check(lib().rt_bvh_build(self.input.ctypes.data, len(self.input), C.byref(h)))
+        build = lib().rt_bvh_build_sah_binning if sah_binning else lib().rt_bvh_build
+        check(build(self.input.ctypes.data, len(self.input), C.byref(h)))
         self.h = h
 
     def __del__(self):
@@ -220,9 +222,9 @@ class Scene:
             self.set_texture(m, img)
 
     @classmethod
-    def from_triangles(cls, prims25, materials, lights, spheres=None, textures=None):
-        """Scene triangles in gather order -> rt_bvh_build -> rt_scene_create."""
-        bvh = Bvh(prims25)
+    def from_triangles(cls, prims25, materials, lights, spheres=None, textures=None, sah_binning=False):
+        """Scene triangles in gather order -> rt_bvh_build (or rt_bvh_build_sah_binning) -> rt_scene_create."""
+        bvh = Bvh(prims25, sah_binning)
         s = cls(bvh.nodes(), bvh.primitives(), bvh.primitive_ids(), materials, lights, spheres, textures)
         s.bvh = bvh
         return s

@@ -39,6 +39,68 @@ struct Builder {
     std::vector<uint32_t> order;        // working permutation of input indices
     std::vector<std::pair<float, uint32_t>> keys;
     rt_bvh* out;
+    bool sahBinning = false; // features.extra.enableBvhSahBinning (src/common.h:63)
+    bool undefined = false;  // a span's centroids coincide on its split axis: the reference's bin index is 0/0 there
+    std::vector<float> leftArea; // surface area of the box around the first k primitives of the sorted span
+
+    static float surfaceArea(vec3 lower, vec3 upper) // calculateAABBSurfaceArea (src/extra.cpp:609-613)
+    {
+        const float x = fabsf(upper.x - lower.x), y = fabsf(upper.y - lower.y), z = fabsf(upper.z - lower.z);
+        return 2.0f * (x * y + x * z + y * z);
+    }
+
+    // splitPrimitivesBySAHBin (src/extra.cpp:623-699) on a span already sorted along the axis (keys[] holds its
+    // centroid coordinates in order).  The reference files the primitives into up to 50 bins of equal width over
+    // the centroid interval and prices a split after every bin as 1.5 + (area x count, left and right) / area of
+    // the span's box, recomputing both boxes each time; here the boxes grow by one primitive per step from either
+    // end (min / max are exact, so the areas are the same floats).  Returns 0 for "no split: leaf".
+    size_t sahSplit(const uint32_t* idx, size_t n, const RefNode& node)
+    {
+        const size_t nBins = n < 50 ? n : 50;
+        const float first = keys[0].first, len = keys[n - 1].first - first;
+        leftArea.resize(n + 1);
+        vec3 lower = splat(FLT_MAX), upper = splat(-FLT_MAX);
+        for (size_t k = 0; k < n; k++) {
+            lower = gmin(lower, lo[idx[k]]);
+            upper = gmax(upper, hi[idx[k]]);
+            leftArea[k + 1] = surfaceArea(lower, upper);
+        }
+        const float outer = surfaceArea(load3(node.lower), load3(node.upper));
+        // walk the candidate splits from the right so that the right-hand box grows with them, keep the cheapest;
+        // among equal costs the reference keeps the leftmost split (strict < while scanning left to right)
+        float minCost = FLT_MAX;
+        size_t minIndex = 0;
+        lower = splat(FLT_MAX), upper = splat(-FLT_MAX);
+        size_t covered = n; // primitives [covered, n) are inside the right-hand box
+        size_t k = n;       // primitives [k, n) are known to lie in bins above the current one
+        for (size_t bin = nBins - 1; bin >= 1; bin--) {
+            // leftSize of the split after bin-1 = number of primitives in bins < bin
+            while (k > 0) {
+                const float q = float(nBins) * (keys[k - 1].first - first) / len; // determineBucketIndex (src/extra.cpp:582-607)
+                if (!(q >= 0.0f && q < 1.0e9f)) {
+                    undefined = true;
+                    return 0;
+                }
+                size_t b = size_t(q);
+                if (b == nBins) b--;
+                if (b < bin) break;
+                k--;
+            }
+            const size_t leftSize = k;
+            while (covered > leftSize) {
+                covered--;
+                lower = gmin(lower, lo[idx[covered]]);
+                upper = gmax(upper, hi[idx[covered]]);
+            }
+            const float cost = 1.5f + (leftArea[leftSize] * float(leftSize) + surfaceArea(lower, upper) * float(n - leftSize)) / outer;
+            if (cost <= minCost) { // <= while scanning right to left: the leftmost of equal costs wins; NaN never does
+                minCost = cost;
+                minIndex = leftSize;
+            }
+        }
+        if (minCost >= float(n)) return 0;
+        return minIndex;
+    }
 
     void emitLeafCopy(const uint32_t* idx, size_t n)
     {
@@ -64,22 +126,25 @@ struct Builder {
             node.lower[0] = lower.x, node.lower[1] = lower.y, node.lower[2] = lower.z;
             node.upper[0] = upper.x, node.upper[1] = upper.y, node.upper[2] = upper.z;
         }
-        if (n <= 4) {
+        auto leaf = [&]() {
             // The reference appends the leaf's primitives, records the offset AFTER that append, then
-            // appends them again (src/bvh.cpp:387-392, 458): primitives() holds every leaf twice and
+            // appends them again (src/bvh.cpp:387-392, 458 / 492-493): primitives() holds every leaf twice and
             // the recorded offset addresses the second copy.  Kept so nodes()/primitives() read the same.
             emitLeafCopy(idx, n);
             node.data[0] = uint32_t(out->prims.size()) | kLeafBit;
             node.data[1] = uint32_t(n);
             out->nodes[nodeIndex] = node;
             emitLeafCopy(idx, n);
+        };
+        if (n <= 4) {
+            leaf();
             return;
         }
         // computeAABBLongestAxis (src/bvh.cpp:160-169): ties go to the lower axis index
         const float ax = fabsf(node.upper[0] - node.lower[0]), ay = fabsf(node.upper[1] - node.lower[1]),
                     az = fabsf(node.upper[2] - node.lower[2]);
         const int axis = (ax >= ay && ax >= az) ? 0 : ((ay >= ax && ay >= az) ? 1 : 2);
-        // splitPrimitivesByMedian (src/bvh.cpp:181-214)
+        // splitPrimitivesByMedian (src/bvh.cpp:181-214); the SAH split sorts the same way first (src/extra.cpp:643)
         keys.resize(n);
         for (size_t i = 0; i < n; i++) {
             const vec3 c = centroid[idx[i]];
@@ -88,7 +153,14 @@ struct Builder {
         std::sort(keys.begin(), keys.end(),
                   [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first < b.first; });
         for (size_t i = 0; i < n; i++) idx[i] = keys[i].second;
-        const size_t split = (n + 1) / 2;
+        size_t split = (n + 1) / 2;
+        if (sahBinning) { // src/bvh.cpp:472-495: a span the heuristic does not split becomes a leaf of any size
+            split = sahSplit(idx, n, node);
+            if (split == 0) {
+                leaf();
+                return;
+            }
+        }
         const uint32_t left = uint32_t(out->nodes.size());
         out->nodes.emplace_back();
         const uint32_t right = uint32_t(out->nodes.size());
@@ -573,7 +645,10 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_error; }
 
-int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out)
+static int bvh_build(const void* prims, uint32_t nPrims, bool sahBinning, rt_bvh** out);
+int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out) { return bvh_build(prims, nPrims, false, out); }
+int rt_bvh_build_sah_binning(const void* prims, uint32_t nPrims, rt_bvh** out) { return bvh_build(prims, nPrims, true, out); }
+static int bvh_build(const void* prims, uint32_t nPrims, bool sahBinning, rt_bvh** out)
 {
     if (!out || (nPrims && !prims)) {
         set_error("rt_bvh_build: null argument");
@@ -609,7 +684,14 @@ int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out)
     dummy.lower[0] = dummy.lower[1] = dummy.lower[2] = 0.0f;
     dummy.upper[0] = dummy.upper[1] = dummy.upper[2] = 1.0f;
     dummy.data[0] = dummy.data[1] = 0;
+    bl.sahBinning = sahBinning;
     bl.build(bl.order.data(), nPrims, 0);
+    if (bl.undefined) {
+        delete b;
+        set_error("rt_bvh_build_sah_binning: more than four triangles share their centroid coordinate on the split axis; the "
+                  "reference's bin index (src/extra.cpp:590-598) is 0/0 converted to size_t for them, which is undefined");
+        return RT_ERR_INVALID;
+    }
     countLevelsAndLeaves(*b);
     *out = b;
     return RT_OK;

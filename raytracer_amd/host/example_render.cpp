@@ -48,7 +48,7 @@ Scene exampleScene()
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: %s <out.rgbf32> [width height startDepth glossySamples]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <out.rgbf32> [width height startDepth glossySamples sahBinning]\n", argv[0]);
         return 2;
     }
     const int W = argc > 2 ? std::atoi(argv[2]) : 256, H = argc > 3 ? std::atoi(argv[3]) : 192;
@@ -62,6 +62,7 @@ int main(int argc, char** argv)
         features.extra.enableGlossyReflection = glossy > 0;
         features.extra.numGlossySamples = glossy > 0 ? (uint32_t)glossy : 1;
         features.extra.enableBloomEffect = true;
+        features.extra.enableBvhSahBinning = argc > 6 && std::atoi(argv[6]) != 0;
         const BVH bvh(scene, features);
         const float kRad = 0.01745329251994329576923690768489f;
         const Trackball camera((float)W / (float)H, 50.0f * kRad, { 0, 0, 0 }, 3.0f, 20.0f * kRad, 20.0f * kRad);

@@ -85,7 +85,7 @@ rt_features toDevice(const Features& f)
 }
 
 // Gathers the scene's triangles in mesh order, then triangle order (src/bvh.cpp:63-74)
-BVH::BVH(const Scene& scene, const Features&)
+BVH::BVH(const Scene& scene, const Features& features)
 {
     std::vector<Primitive> gathered;
     for (uint32_t m = 0; m < scene.meshes.size(); m++) {
@@ -94,7 +94,10 @@ BVH::BVH(const Scene& scene, const Features&)
         for (const uvec3& t : mesh.triangles) gathered.push_back(Primitive { m, mesh.vertices[t.x], mesh.vertices[t.y], mesh.vertices[t.z] });
     }
     rt_bvh* h = nullptr;
-    check(rt_bvh_build(gathered.data(), (uint32_t)gathered.size(), &h), "rt_bvh_build");
+    if (features.extra.enableBvhSahBinning) // src/bvh.cpp:472-499
+        check(rt_bvh_build_sah_binning(gathered.data(), (uint32_t)gathered.size(), &h), "rt_bvh_build_sah_binning");
+    else
+        check(rt_bvh_build(gathered.data(), (uint32_t)gathered.size(), &h), "rt_bvh_build");
     const auto* n = static_cast<const Node*>(rt_bvh_nodes(h));
     const auto* p = static_cast<const Primitive*>(rt_bvh_primitives(h));
     m_nodes.assign(n, n + rt_bvh_num_nodes(h));

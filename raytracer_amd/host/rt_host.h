@@ -79,6 +79,7 @@ struct ExtraFeatures {
     uint32_t bloomFilterSize = 15;
     float bloomFilterThreshold = 0.5f, bloomFilterIntensity = 0.8f;
     uint32_t numGlossySamples = 1;
+    bool enableBvhSahBinning = false; // BVH::BVH splits spans by splitPrimitivesBySAHBin instead of at the median (src/common.h:63)
 };
 struct Features {
     bool enableShading = false, enableReflections = false, enableShadows = false, enableNormalInterp = false;
@@ -131,7 +132,8 @@ struct RenderState {
     const BVHInterface& bvh;
 };
 
-// BVH::BVH(scene, features): the reference's median-split build (rt_bvh_build), kept on the host in the
+// BVH::BVH(scene, features): the reference's build - median splits (rt_bvh_build) or, with
+// features.extra.enableBvhSahBinning, SAH-binned ones (rt_bvh_build_sah_binning) - kept on the host in the
 // reference layout for nodes() / primitives(), and flattened + uploaded once for the device path.
 class BVH : public BVHInterface {
 public:

@@ -63,6 +63,7 @@ def lib():
     L.orc_scene_create.argtypes = [u32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32]
     L.orc_scene_destroy.argtypes = [C.c_void_p]
     L.orc_set_shadow_walk_cap.argtypes = [C.c_int]
+    L.orc_scene_rebuild_bvh.argtypes = [C.c_void_p, C.c_int]
     for n in ("orc_bvh_num_nodes", "orc_bvh_num_prims", "orc_bvh_num_levels", "orc_bvh_num_leaves"):
         getattr(L, n).restype = C.c_uint32
         getattr(L, n).argtypes = [C.c_void_p]
@@ -126,7 +127,7 @@ def make_camera(W, H, fov_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20.0, 
 
 
 class OracleScene:
-    def __init__(self, prims, materials, lights, spheres=None, textures=None):
+    def __init__(self, prims, materials, lights, spheres=None, textures=None, sah_binning=False):
         L = lib()
         self.prims = np.ascontiguousarray(prims, np.uint32).reshape(-1, 25)
         self.materials = np.ascontiguousarray(materials, np.float32).reshape(-1, 9)
@@ -136,6 +137,8 @@ class OracleScene:
                                     _ptr(self.lights, f32p), len(self.lights), _ptr(self.spheres, f32p), len(self.spheres))
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
+        if sah_binning and L.orc_scene_rebuild_bvh(self.h, 1) != 0:
+            raise RuntimeError("orc_scene_rebuild_bvh: a span's centroids coincide on its split axis (undefined in the reference)")
         for m, img in (textures or {}).items():  # {mesh index: (H, W, 3) float32, rows as decoded}
             a = np.ascontiguousarray(img, np.float32)
             if L.orc_scene_set_texture(self.h, int(m), _ptr(a, f32p), a.shape[1], a.shape[0]) != 0:

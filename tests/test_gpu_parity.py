@@ -45,6 +45,17 @@ def scene_pair(name):
     return _scene_cache[name]
 
 
+def sah_scene_pair(name):
+    """The same scenes with the caller's tree built by the reference's SAH-binned split (features.extra.enableBvhSahBinning)."""
+    key = name + "/sah"
+    if key not in _scene_cache:
+        sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.preset(name)
+        g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=True)
+        o = O.OracleScene(sc["prims"], sc["materials"], sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=True)
+        _scene_cache[key] = (g, o, sc)
+    return _scene_cache[key]
+
+
 def rmse(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     return np.sqrt((d * d).mean(axis=(0, 1)))
@@ -84,6 +95,48 @@ def test_primary_hits_and_phong_frame(name, W, H, flags):
     assert_ray_counts(rg["stats"], ro["stats"], name)
     assert rg["stats"].pixels == W * H and rg["stats"].stackOverflows == 0
     assert np.count_nonzero(rg["prim"] != api.NO_HIT) > 0.02 * W * H  # the object is in frame
+
+
+@pytest.mark.parametrize("name,W,H", [("cube", 192, 192), ("cornell", 384, 384), ("monkey", 480, 270), ("teapot", 480, 270), ("knot", 480, 270)])
+@pytest.mark.parametrize("flags", [0, api.RT_RENDER_NO_CULL, api.RT_RENDER_SERIAL, api.RT_RENDER_REFERENCE_TREE])
+def test_frames_in_the_sah_binned_tree(name, W, H, flags):
+    """The reference's other BVH (src/bvh.cpp:472-495, src/extra.cpp:623-699) as the caller's tree: other boxes, another visiting
+    order, leaves of up to 21 triangles in these scenes (the cube is one leaf of 12).  Same bar as for the median tree."""
+    g, o, _ = sah_scene_pair(name)
+    leaf_sizes = g.bvh.nodes()[(g.bvh.nodes()[:, 6] >> 31) == 1][:, 7]
+    assert leaf_sizes.max() > 4 or name == "knot"
+    fg, fo = both_features()
+    cg, co = both_cameras(W, H)
+    rg = g.render_image(cg, fg, W, H, start_depth=4, flags=flags)
+    ro = o.render(co, fo, W, H, start_depth=4)
+    compare_frames(rg, ro, f"{name} sah-binned {W}x{H} flags={flags}")
+    assert_ray_counts(rg["stats"], ro["stats"], name)
+    assert rg["stats"].pixels == W * H and rg["stats"].stackOverflows == 0
+    assert np.count_nonzero(rg["prim"] != api.NO_HIT) > 0.02 * W * H
+
+
+def test_sah_binned_tree_walk_and_glossy_frames():
+    """Without culling the GPU walks exactly the node pairs and triangle tests of the reference's walk in the SAH-binned tree;
+    glossy multi-sample frames in that tree consume the sampler in the reference's order."""
+    g, o, _ = sah_scene_pair("monkey")
+    fg, fo = both_features()
+    cg, co = both_cameras(320, 180)
+    rg = g.render_image(cg, fg, 320, 180, start_depth=2, flags=api.RT_RENDER_NO_CULL | api.RT_RENDER_COUNT_WORK)
+    ro = o.render(co, fo, 320, 180, start_depth=2, want_ids=False)
+    assert rg["stats"].nodePairSteps == ro["stats"]["node_pairs"]
+    assert rg["stats"].triangleTests == ro["stats"]["tri_tests"]
+    gm, om, _ = scene_pair("monkey")
+    rm = om.render(co, fo, 320, 180, start_depth=2, want_ids=False)
+    print("walk of the sah-binned tree:", ro["stats"]["node_pairs"], "pairs,", ro["stats"]["tri_tests"], "tests; of the median tree:",
+          rm["stats"]["node_pairs"], "pairs,", rm["stats"]["tri_tests"], "tests")
+    for name, W, H, n in (("cornell", 192, 192, 4), ("knot", 240, 136, 3), ("teapot", 240, 136, 2)):
+        g, o, _ = sah_scene_pair(name)
+        fg, fo = both_features(enableGlossyReflection=1, numGlossySamples=n)
+        cg, co = both_cameras(W, H)
+        rg, ro = g.render_image(cg, fg, W, H, start_depth=2), o.render(co, fo, W, H, start_depth=2)
+        compare_frames(rg, ro, f"{name} sah-binned glossy x{n}")
+        got, want = rg["stats"].rays, ro["stats"]["primary"] + ro["stats"]["shadow"] + ro["stats"]["secondary"]
+        assert abs(got - want) <= max(1, 1e-4 * want), (got, want)
 
 
 def test_work_counters_match_reference_traversal():
@@ -834,6 +887,13 @@ def test_cpp_host_interface_renders_the_same_frame(tmp_path):
     st = rg["stats"]
     assert f"rays primary {st.primaryRays} shadow {st.shadowRays} secondary {st.secondaryRays}" in log
     assert "probe hit 1 t 1.5 normal 0 1 0" in log
+    # the same program with features.extra.enableBvhSahBinning: BVH::BVH builds the reference's other tree
+    out2 = tmp_path / "frame_sah.rgbf32"
+    log2 = subprocess.run([exe, str(out2), str(W), str(H), "2", "3", "1"], check=True, capture_output=True, text=True, timeout=120).stdout
+    g2 = api.Scene.from_triangles(prims, mats, lights, np.zeros((0, 12), np.float32), sah_binning=True)
+    assert f"nodes {g2.bvh.num_nodes} primitives {g2.bvh.num_primitives} levels {g2.bvh.num_levels} leaves {g2.bvh.num_leaves}" in log2, log2
+    r2 = g2.render_image(cg, fg, W, H, start_depth=2)
+    assert np.array_equal(np.fromfile(out2, np.float32).reshape(H, W, 3).view(np.uint32), r2["rgb"].view(np.uint32))
 
 
 @pytest.mark.parametrize("flags", [0, api.RT_RENDER_SERIAL])
