@@ -1,0 +1,156 @@
+"""Randomised differential test of the HIP path against the CPU oracle: scenes, trees, cameras (also inside the model),
+feature combinations, frame sizes, start depths and flags drawn from a seed; every case is held to the bar of
+test_gpu_parity.py.  Used by test_gpu_fuzz.py (a fixed set of seeds) and from the command line for longer runs:
+
+    python tests/fuzz_parity.py <first seed> <count>      ->  one line per case, failures at the end (exit status 1)
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _oracle as O  # noqa: E402
+from raytracer_amd import api, scenes  # noqa: E402
+
+RMSE_TOL = 1e-3
+SCENES = ["cornell", "cornell_plight", "cube", "monkey", "teapot", "spheres", "knot", "teapot+monkey", "monkey+spheres"]
+_cache = {}
+
+
+def scene_arrays(name):
+    if name == "knot":
+        return scenes.dragon_standin(n_u=120, n_v=24)
+    if "+" in name:
+        return scenes.merge(*[scenes.preset(n) for n in name.split("+")])
+    return scenes.preset(name)
+
+
+def scene_pair(name, sah, transparent):
+    key = (name, sah, transparent)
+    if key not in _cache:
+        if len(_cache) > 12:
+            _cache.clear()
+        sc = scene_arrays(name)
+        mats = sc["materials"].copy()
+        if transparent:
+            mats[::2, 7] = 0.6  # every other mesh lets 60 % through
+            mats[1::3, 7] = 0.25
+        g = api.Scene.from_triangles(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=sah)
+        o = O.OracleScene(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=sah)
+        _cache[key] = (g, o)
+    return _cache[key]
+
+
+def draw_case(seed):
+    r = np.random.default_rng(seed)
+    c = dict(seed=seed)
+    c["scene"] = SCENES[r.integers(len(SCENES))]
+    c["sah"] = bool(r.random() < 0.3) and c["scene"] != "spheres"
+    c["W"], c["H"] = int(r.integers(48, 200)), int(r.integers(32, 140))
+    c["cam"] = dict(fov_deg=float(r.choice([25.0, 50.0, 80.0, 110.0])), dist=float(r.choice([0.05, 0.4, 1.2, 3.0, 6.0])),
+                    look_at=tuple(float(x) for x in r.uniform(-0.4, 0.4, 3)) if r.random() < 0.5 else (0.0, 0.0, 0.0),
+                    rot_deg=(float(r.uniform(-89, 89)), float(r.uniform(-180, 180)), 0.0))
+    f = dict(enableShading=int(r.random() < 0.9), shadingModel=int(r.integers(4)), enableShadows=int(r.random() < 0.7),
+             enableReflections=int(r.random() < 0.75), enableNormalInterp=int(r.random() < 0.7), enableAccelStructure=1,
+             enableTextureMapping=int(r.random() < 0.3), enableBilinearTextureFiltering=int(r.random() < 0.5),
+             numShadowSamples=int(r.integers(1, 6)))
+    if r.random() < 0.1 and c["scene"] in ("cube", "cornell", "cornell_plight", "spheres"):
+        f["enableAccelStructure"] = 0  # every triangle for every ray: small scenes only
+    if r.random() < 0.5:
+        f["enableGlossyReflection"], f["numGlossySamples"] = 1, int(r.choice([1, 2, 3, 4, 5, 6]))
+    if r.random() < 0.15:
+        f["numPixelSamples"], f["enableJitteredSampling"] = int(r.choice([2, 4, 5])), int(r.random() < 0.5)
+    c["transparent"] = bool(r.random() < 0.2)
+    if c["transparent"]:  # (the reference's walk of a light sample through transparent occluders need not end: shadows off)
+        f["enableTransparency"], f["enableShadows"] = 1, 0
+    if r.random() < 0.3:
+        f["enableBloomEffect"], f["bloomFilterSize"] = 1, int(r.choice([1, 2, 7, 15, 30]))
+        f["bloomFilterThreshold"], f["bloomFilterIntensity"] = float(r.choice([0.2, 0.5, 0.9])), float(r.choice([0.3, 0.8, 1.5]))
+    c["features"] = f
+    c["start_depth"] = int(r.choice([0, 2, 3, 4, 5, 6]))
+    if f.get("numGlossySamples", 1) >= 4 and c["start_depth"] < 2:
+        c["start_depth"] = 2  # keeps the oracle's frame within seconds
+    c["flags"] = int(r.choice([0, 0, 0, api.RT_RENDER_NO_CULL, api.RT_RENDER_REFERENCE_TREE, api.RT_RENDER_SERIAL,
+                               api.RT_RENDER_NO_CULL | api.RT_RENDER_REFERENCE_TREE]))
+    c["frames"] = int(r.choice([1, 1, 1, 2, 5]))  # more than one: rt_render_images, one camera per frame
+    return c
+
+
+def run_case(c):
+    """Returns a list of complaints (empty: the case holds)."""
+    g, o = scene_pair(c["scene"], c["sah"], c["transparent"])
+    W, H, f = c["W"], c["H"], c["features"]
+    fg, fo = api.Features(**f), O.make_features(**f)
+    bad = []
+    cams = []
+    for k in range(c["frames"]):
+        kw = dict(c["cam"])
+        kw["rot_deg"] = (kw["rot_deg"][0], kw["rot_deg"][1] + 37.0 * k, 0.0)
+        cams.append((api.camera_from_trackball(W, H, **kw), O.make_camera(W, H, **kw)))
+
+    def want_of(co):
+        ro = o.render(co, fo, W, H, start_depth=c["start_depth"])
+        rgb = ro["rgb"]
+        if f.get("enableBloomEffect"):
+            rgb = O.bloom(rgb, f["bloomFilterSize"], f["bloomFilterThreshold"], f["bloomFilterIntensity"])
+        return ro, rgb
+
+    def rmse_of(a, b):
+        d = a.astype(np.float64) - b.astype(np.float64)
+        return np.sqrt((d * d).mean(axis=(0, 1)))
+
+    if c["frames"] == 1:
+        rg = g.render_image(cams[0][0], fg, W, H, start_depth=c["start_depth"], flags=c["flags"])
+        ro, want = want_of(cams[0][1])
+        n = W * H
+        id_bad = int(np.count_nonzero(rg["prim"] != ro["prim"]))
+        t_bad = int(np.count_nonzero(rg["t"].view(np.uint32) != ro["t"].view(np.uint32)))
+        if id_bad or t_bad:
+            bad.append(f"primary hits differ: {id_bad} ids, {t_bad} distances of {n}")
+        got = (rg["stats"].primaryRays, rg["stats"].shadowRays, rg["stats"].secondaryRays)
+        exp = (ro["stats"]["primary"], ro["stats"]["shadow"], ro["stats"]["secondary"])
+        if any(abs(a - b) > max(1, 1e-4 * b) for a, b in zip(got, exp)):
+            bad.append(f"ray counts {got} against {exp}")
+        if rg["stats"].stackOverflows:
+            bad.append("stack overflows")
+        e = rmse_of(rg["rgb"], want)
+        if not (e <= RMSE_TOL).all() or not np.isfinite(rg["rgb"]).all():
+            bad.append(f"rgb rmse {e}, max abs {np.abs(rg['rgb'] - want).max():.3g}")
+    else:
+        rs = g.render_images([cg for cg, _ in cams], fg, W, H, start_depth=c["start_depth"], flags=c["flags"])
+        for k, (_, co) in enumerate(cams):
+            _, want = want_of(co)
+            e = rmse_of(rs["rgb"][k], want)
+            if not (e <= RMSE_TOL).all() or not np.isfinite(rs["rgb"][k]).all():
+                bad.append(f"frame {k}: rgb rmse {e}, max abs {np.abs(rs['rgb'][k] - want).max():.3g}")
+    return bad
+
+
+def describe(c):
+    f = c["features"]
+    on = [k.replace("enable", "") for k, v in f.items() if k.startswith("enable") and v]
+    return (f"seed {c['seed']}: {c['scene']}{' sah' if c['sah'] else ''}{' transparent' if c['transparent'] else ''} {c['W']}x{c['H']} x{c['frames']} depth "
+            f"{c['start_depth']} flags {c['flags']} fov {c['cam']['fov_deg']} dist {c['cam']['dist']} model {f['shadingModel']} glossy "
+            f"{f.get('numGlossySamples', 0) if f.get('enableGlossyReflection') else 0} spp {f.get('numPixelSamples', 1)} [{' '.join(on)}]")
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    failures = []
+    for seed in range(first, first + count):
+        c = draw_case(seed)
+        try:
+            bad = run_case(c)
+        except Exception as e:  # an error return is a finding too
+            bad = [f"{type(e).__name__}: {e}"]
+        print(("FAIL " if bad else "ok   ") + describe(c) + ("  -> " + "; ".join(bad) if bad else ""), flush=True)
+        if bad:
+            failures.append(seed)
+    print(f"{count - len(failures)} of {count} cases hold; failing seeds: {failures}", flush=True)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
