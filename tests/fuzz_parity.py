@@ -2,7 +2,10 @@
 feature combinations, frame sizes, start depths and flags drawn from a seed; every case is held to the bar of
 test_gpu_parity.py.  Used by test_gpu_fuzz.py (a fixed set of seeds) and from the command line for longer runs:
 
-    python tests/fuzz_parity.py <first seed> <count>      ->  one line per case, failures at the end (exit status 1)
+    python tests/fuzz_parity.py <first seed> <count> [big]   ->  one line per case, failures at the end (exit status 1)
+
+`big`: frames of 1280x720 and 1920x1080 on the large scenes, up to four per call - the sizes at which the library changes its
+schedule (one ray per lane, hand-over, large-sequence settings).
 """
 import os
 import sys
@@ -22,6 +25,8 @@ _cache = {}
 def scene_arrays(name):
     if name == "knot":
         return scenes.dragon_standin(n_u=120, n_v=24)
+    if name == "dragon":
+        return scenes.dragon_standin()
     if "+" in name:
         return scenes.merge(*[scenes.preset(n) for n in name.split("+")])
     return scenes.preset(name)
@@ -43,12 +48,15 @@ def scene_pair(name, sah, transparent):
     return _cache[key]
 
 
-def draw_case(seed):
+def draw_case(seed, big=False):
     r = np.random.default_rng(seed)
     c = dict(seed=seed)
     c["scene"] = SCENES[r.integers(len(SCENES))]
     c["sah"] = bool(r.random() < 0.3) and c["scene"] != "spheres"
     c["W"], c["H"] = int(r.integers(48, 200)), int(r.integers(32, 140))
+    if big:
+        c["scene"] = str(r.choice(["dragon", "dragon", "knot", "teapot+monkey"]))
+        c["W"], c["H"] = (1920, 1080) if r.random() < 0.6 else (1280, 720)
     c["cam"] = dict(fov_deg=float(r.choice([25.0, 50.0, 80.0, 110.0])), dist=float(r.choice([0.05, 0.4, 1.2, 3.0, 6.0])),
                     look_at=tuple(float(x) for x in r.uniform(-0.4, 0.4, 3)) if r.random() < 0.5 else (0.0, 0.0, 0.0),
                     rot_deg=(float(r.uniform(-89, 89)), float(r.uniform(-180, 180)), 0.0))
@@ -75,6 +83,14 @@ def draw_case(seed):
     c["flags"] = int(r.choice([0, 0, 0, api.RT_RENDER_NO_CULL, api.RT_RENDER_REFERENCE_TREE, api.RT_RENDER_SERIAL,
                                api.RT_RENDER_NO_CULL | api.RT_RENDER_REFERENCE_TREE]))
     c["frames"] = int(r.choice([1, 1, 1, 2, 5]))  # more than one: rt_render_images, one camera per frame
+    if big:
+        c["frames"] = int(r.choice([1, 1, 2, 4]))
+        c["cam"]["dist"] = float(r.choice([0.4, 1.2, 3.0]))
+        f.pop("numPixelSamples", None), f.pop("enableJitteredSampling", None)
+        if f.get("numGlossySamples", 1) > 4:
+            f["numGlossySamples"] = 4
+        if c["flags"] & api.RT_RENDER_SERIAL:
+            c["flags"] = 0
     return c
 
 
@@ -102,13 +118,15 @@ def run_case(c):
         return np.sqrt((d * d).mean(axis=(0, 1)))
 
     if c["frames"] == 1:
+        n = W * H
         rg = g.render_image(cams[0][0], fg, W, H, start_depth=c["start_depth"], flags=c["flags"])
         ro, want = want_of(cams[0][1])
-        n = W * H
         id_bad = int(np.count_nonzero(rg["prim"] != ro["prim"]))
         t_bad = int(np.count_nonzero(rg["t"].view(np.uint32) != ro["t"].view(np.uint32)))
-        if id_bad or t_bad:
+        if id_bad > 1e-4 * n or t_bad > 1e-4 * n or ((id_bad or t_bad) and n < 500000):
             bad.append(f"primary hits differ: {id_bad} ids, {t_bad} distances of {n}")
+        elif id_bad or t_bad:  # within the bar of 99.99 %: reported, not failed
+            print(f"note seed {c['seed']}: {id_bad} primary ids, {t_bad} distances of {n} differ", flush=True)
         got = (rg["stats"].primaryRays, rg["stats"].shadowRays, rg["stats"].secondaryRays)
         exp = (ro["stats"]["primary"], ro["stats"]["shadow"], ro["stats"]["secondary"])
         if any(abs(a - b) > max(1, 1e-4 * b) for a, b in zip(got, exp)):
@@ -138,9 +156,10 @@ def describe(c):
 
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     failures = []
     for seed in range(first, first + count):
-        c = draw_case(seed)
+        c = draw_case(seed, big)
         try:
             bad = run_case(c)
         except Exception as e:  # an error return is a finding too
