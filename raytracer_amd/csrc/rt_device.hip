@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace rt;
@@ -92,6 +93,16 @@ struct rt_scene {
     uint32_t* d_primId = nullptr;
     float* d_primT = nullptr;
     size_t fbPixels = 0;
+    // rt_render_images: up to four launch sequences in flight, each on a stream of its own with its frames on the device, the
+    // bloom's intermediate image and a pinned host buffer the finished frames are copied into (all sized lazily)
+    struct ImageLane {
+        hipStream_t stream = nullptr;
+        float* d_rgb = nullptr;
+        float* d_scratch = nullptr;
+        float* h_stage = nullptr;
+        size_t frames = 0, px = 0;
+    };
+    ImageLane imageLanes[4];
     bool hasTextures = false;
     GpuTexture* d_textures = nullptr;  // one entry per material (part of no blob: rt_scene_set_texture rewrites entries)
     std::vector<float*> texturePixels; // device copy of each material's texels (null: none)
@@ -1895,6 +1906,12 @@ void rt_scene_destroy(rt_scene* s)
     (void)hipFree(s->d_scratch);
     (void)hipFree(s->d_primId);
     (void)hipFree(s->d_primT);
+    for (rt_scene::ImageLane& l : s->imageLanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        (void)hipFree(l.d_rgb), (void)hipFree(l.d_scratch);
+        if (l.h_stage) (void)hipHostFree(l.h_stage);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+    }
     for (Workspace* w : s->workspaces) free_workspace(w);
     delete s;
 }
@@ -2886,43 +2903,105 @@ int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, con
         }
     RT_HIP(hipSetDevice(scene->device));
     const size_t px = (size_t)width * height;
-    // launch sequences of up to 8 frames and 16.6 M pixels: about 3 KB of task queues and path states per pixel
-    const int perSequence = (int)std::max<size_t>(1, std::min<size_t>(std::min(nFrames, 8), (size_t)(8 * 1920 * 1080) / px));
-    if (px * perSequence > scene->fbPixels) {
-        (void)hipFree(scene->d_rgb), (void)hipFree(scene->d_scratch), (void)hipFree(scene->d_primId), (void)hipFree(scene->d_primT);
-        scene->d_rgb = scene->d_scratch = nullptr, scene->d_primId = nullptr, scene->d_primT = nullptr;
-        scene->fbPixels = 0;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_rgb), px * perSequence * 12));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_scratch), px * perSequence * 12));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primId), px * perSequence * 4));
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&scene->d_primT), px * perSequence * 4));
-        scene->fbPixels = px * perSequence;
+    // The frames go as launch sequences of up to 8 frames and 16.6 M pixels (about 3 KB of task queues and path states per pixel),
+    // up to four of them in flight on streams of their own within 41.5 M pixels in all (20 frames of 1920 x 1080: four sequences
+    // of five): while one sequence's dependent rounds leave the chip half empty another fills it, and the finished frames of a
+    // third are on their way to the host.
+    const size_t kSequencePixels = (size_t)8 * 1920 * 1080, kFlightPixels = (size_t)20 * 1920 * 1080;
+    // (more streams with shorter sequences before fewer with longer ones: 4 x 5 frames render faster than 2 x 8)
+    int lanes = (int)std::max<size_t>(1, std::min<size_t>(std::min(nFrames, 4), kFlightPixels / px));
+    int perSequence = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, kSequencePixels / px), kFlightPixels / ((size_t)lanes * px)));
+    perSequence = std::min(perSequence, (nFrames + lanes - 1) / lanes);
+    lanes = std::min(lanes, (nFrames + perSequence - 1) / perSequence);
+    for (int k = 0; k < lanes; k++) {
+        rt_scene::ImageLane& l = scene->imageLanes[k];
+        if (!l.stream) RT_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        if (l.px * l.frames < px * perSequence || l.px < px) {
+            RT_HIP(hipStreamSynchronize(l.stream));
+            (void)hipFree(l.d_rgb), (void)hipFree(l.d_scratch);
+            if (l.h_stage) (void)hipHostFree(l.h_stage);
+            l.d_rgb = l.d_scratch = l.h_stage = nullptr, l.frames = l.px = 0;
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&l.d_rgb), px * perSequence * 12));
+            RT_HIP(hipMalloc(reinterpret_cast<void**>(&l.d_scratch), px * 12));
+            RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&l.h_stage), px * perSequence * 12, hipHostMallocDefault));
+            l.frames = (size_t)perSequence, l.px = px;
+        }
     }
+    struct Pending {
+        int first = 0, n = 0;
+        uint32_t flags = 0;
+        bool active = false;
+    } pending[4];
     rt_stats total {};
-    for (int first = 0; first < nFrames; first += perSequence) {
-        const int n = std::min(perSequence, nFrames - first);
-        uint32_t fl = flags;
+    // queues lane k's sequence: render, bloom (src/render.cpp:48-50), copy to the lane's pinned buffer
+    auto launch = [&](int k, int first, int n, uint32_t fl) -> int {
+        rt_scene::ImageLane& l = scene->imageLanes[k];
+        int rc = rt_render_frames(scene, cameras + first, n, features, width, height, startDepth, nullptr, fl, l.d_rgb, nullptr, nullptr, l.stream);
+        for (int f = 0; rc == RT_OK && features->enableBloomEffect && f < n; f++)
+            rc = rt_bloom(l.d_rgb + 3 * px * f, l.d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,
+                          features->bloomFilterIntensity, nullptr, l.stream);
+        if (rc == RT_OK) RT_HIP(hipMemcpyAsync(l.h_stage, l.d_rgb, px * n * 12, hipMemcpyDeviceToHost, l.stream));
+        return rc;
+    };
+    // waits for lane k's sequence, renders it again where the library asks for that, and hands its frames to the caller
+    auto collect = [&](int k) -> int {
+        Pending& p = pending[k];
+        if (!p.active) return RT_OK;
+        p.active = false;
+        rt_scene::ImageLane& l = scene->imageLanes[k];
         rt_stats st {};
-        int rc = RT_OK;
-        for (int attempt = 0; attempt < 5; attempt++) {
-            rc = rt_render_frames(scene, cameras + first, n, features, width, height, startDepth, nullptr, fl, scene->d_rgb, nullptr, nullptr, nullptr);
-            for (int f = 0; rc == RT_OK && features->enableBloomEffect && f < n; f++) // src/render.cpp:48-50
-                rc = rt_bloom(scene->d_rgb + 3 * px * f, scene->d_scratch, width, height, features->bloomFilterSize, features->bloomFilterThreshold,
-                              features->bloomFilterIntensity, nullptr, nullptr);
-            if (rc == RT_OK) rc = rt_sync(scene, nullptr, &st);
-            if (rc == RT_ERR_AGAIN && attempt < 3) continue; // the task queues have grown: render the sequence again
-            if ((rc == RT_ERR_LIMIT || rc == RT_ERR_AGAIN) && !(fl & RT_RENDER_SERIAL)) { // beyond the default pipeline's limits: depth-first instead
-                fl |= RT_RENDER_SERIAL;
-                continue;
+        int rc = rt_sync(scene, l.stream, &st);
+        for (int attempt = 0; rc != RT_OK && attempt < 5; attempt++) {
+            if (rc == RT_ERR_AGAIN && attempt < 3) { // the task queues have grown: render the sequence again
+            } else if ((rc == RT_ERR_LIMIT || rc == RT_ERR_AGAIN) && !(p.flags & RT_RENDER_SERIAL)) { // beyond the default pipeline's limits: depth-first instead
+                p.flags |= RT_RENDER_SERIAL;
+            } else {
+                break;
             }
-            break;
+            rc = launch(k, p.first, p.n, p.flags);
+            if (rc == RT_OK) rc = rt_sync(scene, l.stream, &st);
         }
         if (rc != RT_OK) return rc;
-        for (int f = 0; f < n; f++) RT_HIP(hipMemcpy(rgb[first + f], scene->d_rgb + 3 * px * f, px * 12, hipMemcpyDeviceToHost));
+        // out of the pinned buffer into the caller's images: one thread moves a 1080p frame in 1.4 ms, which a sweep's last
+        // sequences would wait for frame after frame - several threads, a slice of every frame each
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int workers = (px * p.n * 12 < ((size_t)4 << 20)) ? 1 : (int)std::min(8u, std::max(1u, hw));
+        auto copySlice = [&](int t) {
+            const size_t lo = px * 12 * (size_t)t / workers & ~(size_t)63, hi = (t + 1 == workers) ? px * 12 : (px * 12 * (size_t)(t + 1) / workers & ~(size_t)63);
+            for (int f = 0; f < p.n; f++)
+                memcpy(reinterpret_cast<char*>(rgb[p.first + f]) + lo, reinterpret_cast<const char*>(l.h_stage + 3 * px * f) + lo, hi - lo);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < workers; t++) pool.emplace_back(copySlice, t);
+        copySlice(0);
+        for (std::thread& th : pool) th.join();
         total.primaryRays += st.primaryRays, total.shadowRays += st.shadowRays, total.secondaryRays += st.secondaryRays;
         total.nodePairSteps += st.nodePairSteps, total.triangleTests += st.triangleTests, total.queryNodeSteps += st.queryNodeSteps;
         total.pixels += st.pixels, total.stackOverflows += st.stackOverflows, total.referenceTreeQueries += st.referenceTreeQueries;
         total.pipeline = st.pipeline;
+        return RT_OK;
+    };
+    auto drain = [&](int rc) { // an error: nothing of this call stays queued
+        for (int k = 0; k < lanes; k++) (void)hipStreamSynchronize(scene->imageLanes[k].stream);
+        return rc;
+    };
+    uint32_t fl = flags | (lanes > 1 ? (uint32_t)RT_RENDER_OVERLAPPED : 0u);
+    int i = 0;
+    for (int first = 0; first < nFrames; first += perSequence, i++) {
+        const int k = i % lanes, n = std::min(perSequence, nFrames - first);
+        int rc = collect(k); // the sequence this lane rendered before
+        if (rc != RT_OK) return drain(rc);
+        rc = launch(k, first, n, fl);
+        if (rc == RT_ERR_LIMIT && !(fl & RT_RENDER_SERIAL)) { // refused before anything was queued (a recursion tree beyond the rounds' limit)
+            fl |= RT_RENDER_SERIAL;
+            rc = launch(k, first, n, fl);
+        }
+        if (rc != RT_OK) return drain(rc);
+        pending[k].first = first, pending[k].n = n, pending[k].flags = fl, pending[k].active = true;
+    }
+    for (int j = 0; j < lanes; j++) { // in the order the sequences were queued
+        const int rc = collect((i + j) % lanes);
+        if (rc != RT_OK) return drain(rc);
     }
     if (stats) *stats = total;
     return RT_OK;
