@@ -2915,7 +2915,13 @@ int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, con
     lanes = std::min(lanes, (nFrames + perSequence - 1) / perSequence);
     for (int k = 0; k < lanes; k++) {
         rt_scene::ImageLane& l = scene->imageLanes[k];
-        if (!l.stream) RT_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        if (!l.stream) {
+            // equal sequences on equal streams run in step, all asking for the same resource at a time: two of the four
+            // streams get the higher of the device's stream priorities and the sequences drift apart
+            int least = 0, greatest = 0;
+            RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            RT_HIP(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, k < 2 ? greatest : least));
+        }
         if (l.px * l.frames < px * perSequence || l.px < px) {
             RT_HIP(hipStreamSynchronize(l.stream));
             (void)hipFree(l.d_rgb), (void)hipFree(l.d_scratch);

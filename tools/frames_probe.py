@@ -5,6 +5,7 @@ A step is one frame: render + bloom + copy to pinned host memory, as in bench.py
   RT_PROBE_WORLD=N       rank 0's stripes of a world of N (no exchange)      RT_PROBE_WORKLOAD=<bench workload>
   RT_PROBE_NO_COPY / RT_PROBE_NO_BLOOM / RT_PROBE_NO_SHADOWS   leave that part out
   RT_PROBE_LONG=m        m times as many sequences                            RT_PROBE_HW_QUEUES=q (default 8)
+  RT_PROBE_PRIORITIES=p0,p1,..  stream k gets priority p[k % len] (-1 = high, 0 = normal)
   RT_PROBE_STAGGER=a,b,c,d  stream k first renders a sequence of that many frames (1 = k + 1): the streams run out of step
 Every configuration gets a scene of its own (a scene keeps one buffer set per stream).
 """
@@ -31,7 +32,8 @@ for spec in sys.argv[1:]:
     K, S = int(parts[0]), int(parts[1])
     fl = api.RT_RENDER_OVERLAPPED if (len(parts) > 2 and "o" in parts[2]) else 0
     scene = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])  # a scene keeps a buffer set per stream: start afresh
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    prio = [int(x) for x in os.environ["RT_PROBE_PRIORITIES"].split(",")] if os.environ.get("RT_PROBE_PRIORITIES") else None
+    streams = [torch.cuda.Stream(device=dev, priority=prio[k % len(prio)]) if prio else torch.cuda.Stream(device=dev) for k in range(S)]
     frames = [torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev) for _ in range(S)]
     scratch = [torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev) for _ in range(S)]
     host = [torch.empty((K, H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(S)]
