@@ -129,7 +129,8 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0: leave the environment's value)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
-    ap.add_argument("--stream-priorities", default="-1,-1,0,0", help="priority of stream k = entry k modulo the list's length (-1: high, 0: normal; '0': all equal)")
+    ap.add_argument("--stream-priorities", default="", help="priority of stream k = entry k modulo the list's length (-1: high, 0: normal; '0': all equal; "
+                                                            "default: the first half of the streams high, e.g. -1,-1,0,0)")
     ap.add_argument("--keep-pooling", action="store_true", help="pool --frames-per-sequence frames even when a frame renders in under 3 ms")
     ap.add_argument("--sequence-sizes", default="", help="frames of the timed launch sequences, in queue order (comma list; default: see sequences())")
     args = ap.parse_args()
@@ -208,9 +209,9 @@ def main():
         del probe
     K = max(1, min(K, (8 * 1920 * 1080 * world) // (W * H)))  # ... within 16.6 M pixels per rank (about 3 KB of queues and path states per pixel)
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
-    # Equal sequences started together on equal streams run in step; with two of four streams at the higher of the GPU's two
-    # stream priorities they drift apart (5 x 4: 4.08-4.10 against 4.20-4.23 ms per frame)
-    prio = [int(x) for x in args.stream_priorities.split(",")] if args.stream_priorities else [0]
+    # Equal sequences started together on equal streams run in step; with half of the streams at the higher of the GPU's two
+    # stream priorities they drift apart (5 x 4: 4.08-4.10 against 4.20-4.23 ms per frame; 10 x 2: 4.08 against 4.53)
+    prio = [int(x) for x in args.stream_priorities.split(",")] if args.stream_priorities else [-1 if k < (F + 1) // 2 else 0 for k in range(F)]
     streams = [torch.cuda.Stream(device=dev, priority=prio[k % len(prio)]) for k in range(F)]
     frames = [torch.zeros((K, H, W, 3), dtype=torch.float32, device=dev) for _ in range(F)]
     scratch = [torch.empty(api.lib().rt_bloom_scratch_bytes(W, H) // 4, dtype=torch.float32, device=dev) for _ in range(F)]
