@@ -13,7 +13,8 @@ rt_render_frames - one launch sequence whose stages trace the rays of all its fr
 elapsed time of the K steps divided by K, `ms_per_frame_alone` what one frame takes with nothing else queued (rt_render).
 With N > 1 every frame is cut into interleaved 8-row stripes, stripe s belongs to rank s % N; the stripes of a sequence
 are exchanged with one all-to-all that leaves frame f whole on rank f % N, which blooms it and copies it to the host:
-every frame of the job ends in host memory once.  Rank 0 prints one JSON line.  `value` counts every closest-hit query
+every frame of the job ends in host memory once (`--partition frames` is the comparison: whole frames dealt to the ranks in turn,
+nothing exchanged).  Rank 0 prints one JSON line.  `value` counts every closest-hit query
 that contributes to the image (primary + shadow + reflection rays) over all ranks, divided by the slowest rank's time.
 """
 import argparse
@@ -131,6 +132,9 @@ def main():
                     help="torch.distributed backend when N > 1: nccl (= RCCL over xGMI) or gloo (stripes staged through host memory)")
     ap.add_argument("--stream-priorities", default="", help="priority of stream k = entry k modulo the list's length (-1: high, 0: normal; '0': all equal; "
                                                             "default: the first half of the streams high, e.g. -1,-1,0,0)")
+    ap.add_argument("--partition", default="stripes", choices=["stripes", "frames"],
+                    help="N > 1: 'stripes' = every frame cut into interleaved 8-row stripes over the ranks + one all-to-all per sequence (the "
+                         "default); 'frames' = whole frames dealt to the ranks in turn, no exchange (the comparison)")
     ap.add_argument("--keep-pooling", action="store_true", help="pool --frames-per-sequence frames even when a frame renders in under 3 ms")
     ap.add_argument("--sequence-sizes", default="", help="frames of the timed launch sequences, in queue order (comma list; default: see sequences())")
     args = ap.parse_args()
@@ -175,13 +179,17 @@ def main():
     cam = api.camera_from_trackball(W, H)
     cams = [api.camera_from_trackball(W, H, rot_deg=(20.0, 20.0 + 360.0 * k / max(args.steps, 1), 0.0)) for k in range(args.steps)] \
         if wl.get("orbit") else None
-    region = api.Region(8, rank, world)
+    by_frames = world > 1 and args.partition == "frames"  # rank r renders frames r, r + N, ... whole; nothing is exchanged
+    region = api.Region(8, 0, 1) if by_frames else api.Region(8, rank, world)
     flags = api.RT_RENDER_NO_CULL if args.no_cull else 0
+    my_steps = len(range(rank, args.steps, world)) if by_frames else args.steps       # frames this rank renders (a share of each, or whole ones)
+    my_warmup = len(range(rank, args.warmup, world)) if by_frames else args.warmup
 
     # One rank of several renders a share of every frame: its stages are small, and fewer, longer sequences serve it better
     # (one rank of eight, 20 steps: 0.73 ms per frame with 2 sequences of 10 in flight, 0.81 ms with 4 of 5).
-    F = max(1, min(8, args.frames_in_flight or (4 if world == 1 else 2)))
-    K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence or (8 if world == 1 else 16), -(-max(args.steps, 1) // F)))  # frames per launch sequence
+    whole = world == 1 or by_frames  # this rank renders whole frames
+    F = max(1, min(8, args.frames_in_flight or (4 if whole else 2)))
+    K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence or (8 if whole else 16), -(-max(my_steps, 1) // F)))  # frames per launch sequence
     if args.sequence_sizes:
         K = max(1, min(api.RT_MAX_FRAMES, max(int(x) for x in args.sequence_sizes.split(","))))
     elif K > 2 and not args.keep_pooling:
@@ -207,7 +215,13 @@ def main():
         if float(probe_ms.item()) < 3.0:
             K = 2
         del probe
-    K = max(1, min(K, (8 * 1920 * 1080 * world) // (W * H)))  # ... within 16.6 M pixels per rank (about 3 KB of queues and path states per pixel)
+    if by_frames:  # every rank cuts its own frames into sequences of the same size: the smallest any rank arrived at
+        kk = torch.tensor([float(K)], dtype=torch.float64)
+        if args.backend == "nccl":
+            kk = kk.to(dev)
+        dist.all_reduce(kk, op=dist.ReduceOp.MIN)
+        K = int(kk.item())
+    K = max(1, min(K, (8 * 1920 * 1080 * (1 if by_frames else world)) // (W * H)))  # ... within 16.6 M pixels per rank (about 3 KB of queues and path states per pixel)
     flags_timed = flags | (api.RT_RENDER_OVERLAPPED if F > 1 else 0)
     # Equal sequences started together on equal streams run in step; with half of the streams at the higher of the GPU's two
     # stream priorities they drift apart (5 x 4: 4.08-4.10 against 4.20-4.23 ms per frame; 10 x 2: 4.08 against 4.53)
@@ -234,7 +248,8 @@ def main():
         """Launch sequence i = frames [first, first + count): queued on stream i % F; nothing waits on the host."""
         k = i % F
         st = streams[k]
-        seq_cams = [cams[(first + f) % len(cams)] for f in range(count)] if cams else [cam] * count
+        step_of = (lambda j: rank + j * world) if by_frames else (lambda j: j)  # which step of the job this rank's j-th frame is
+        seq_cams = [cams[step_of(first + f) % len(cams)] for f in range(count)] if cams else [cam] * count
         last_count[k] = count
         with torch.cuda.stream(st):
             if ev:
@@ -244,7 +259,7 @@ def main():
             if ev:
                 ev[1].record(st)
             mine = range(count)  # the frames this rank completes
-            if world > 1:
+            if world > 1 and not by_frames:
                 if args.backend == "nccl":
                     mine = plans[k].assemble(frames[k][:count], dist)
                 else:  # stripes through host memory: this rank's stripes down, the frames it is the root of up
@@ -256,7 +271,7 @@ def main():
                 for f in mine:
                     api.bloom_device(frames[k][f].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
                                      feat.bloomFilterIntensity, stream=st.cuda_stream)
-            if world == 1:
+            if whole:
                 host[k][:count].copy_(frames[k][:count], non_blocking=True)
             else:
                 for f in mine:
@@ -289,16 +304,16 @@ def main():
             again = bool(flag.item() > 0)
         if not again:
             break
-    for i, (first, count) in enumerate(sequences(args.warmup)):
+    for i, (first, count) in enumerate(sequences(my_warmup)):
         run(i, first, count)
     barrier()
     stats = scene.sync(streams[0].cuda_stream)  # this rank's share of the last sequence queued on stream 0
     stats_frames = last_count[0]
-    timed = sequences(args.steps)
+    timed = sequences(my_steps)
     if args.sequence_sizes:
         sizes = [int(x) for x in args.sequence_sizes.split(",")]
-        if sum(sizes) != args.steps or max(sizes) > K or min(sizes) < 1:
-            raise SystemExit(f"--sequence-sizes must add up to {args.steps} steps, each within 1..{K}")
+        if sum(sizes) != my_steps or max(sizes) > K or min(sizes) < 1:
+            raise SystemExit(f"--sequence-sizes must add up to {my_steps} steps, each within 1..{K}")
         timed = [(sum(sizes[:i]), n) for i, n in enumerate(sizes)]
     timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
     t0 = time.perf_counter()
@@ -337,6 +352,8 @@ def main():
         if args.backend == "nccl":
             rays_rank, tmax = rays_rank.to(dev), tmax.to(dev)
         dist.all_reduce(rays_rank)
+        if by_frames:  # every rank counted whole frames
+            rays_rank = rays_rank / world
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     rays_frame = float(rays_rank[:3].sum().item())
@@ -403,9 +420,10 @@ def main():
                        "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
                        "rays_per_frame": int(rays_frame), "frames_per_sequence": K, "sequences_in_flight": F, "frames_in_flight": K * F,
                        "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "step": "one frame: its share of rt_render_frames" + (" + stripe all-to-all (frame f whole on rank f % N)" if world > 1 else "")
+                       "step": "one frame: its share of rt_render_frames" + (" + stripe all-to-all (frame f whole on rank f % N)" if world > 1 and not by_frames else "")
                                + " + rt_bloom + frame copy to pinned host memory",
-                       "partition": f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-to-all" if world > 1 else ""),
+                       "partition": (f"whole frames dealt to {world} GPUs in turn, no exchange" if by_frames else
+                                     f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-to-all" if world > 1 else "")),
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note,
