@@ -2849,6 +2849,8 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
         rt::set_error("rt_render_image: null argument or empty frame");
         return RT_ERR_INVALID;
     }
+    // the image alone: the camera loop's route for one camera (the frame leaves through pinned memory, copied out by several threads)
+    if (!primId && !primT) return rt_render_images(scene, camera, 1, features, width, height, startDepth, flags, &rgb, stats);
     RT_HIP(hipSetDevice(scene->device));
     const size_t px = (size_t)width * height;
     if (px > scene->fbPixels) {
