@@ -246,8 +246,8 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
  * are rendered by rt_render_frames, up to eight at a time, with up to four such launch sequences in flight on streams the
  * scene owns (within 20 frames' worth of 1920 x 1080 pixels), their finished frames copied out through pinned memory while
  * the next ones render - the throughput of the camera sweep from one blocking call; every image is the one rt_render_image
- * writes for its camera.  stats: the counters of all frames together.  (The streams share the GPU best with
- * GPU_MAX_HW_QUEUES=8 in the process environment; HIP's default is 4 hardware queues.) */
+ * writes for its camera.  stats: the counters of all frames together.  (Two of the four streams are created at the
+ * device's higher stream priority: equal streams with equal work would run in step.) */
 int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width,
                      int height, int startDepth, uint32_t flags, float* const* rgb, rt_stats* stats);
 
