@@ -131,7 +131,7 @@ int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out);
  * interval, the cheapest split after a bin) and a span whose cheapest split is no cheaper than testing all of
  * its triangles becomes a leaf of that many triangles.  RT_ERR_INVALID for input the reference's code is
  * undefined on: more than four triangles with one centroid coordinate on their split axis (the bin index is
- * 0/0 converted to size_t).  rt_scene_create accepts leaves of up to 63 triangles and trees of up to 32 levels. */
+ * 0/0 converted to size_t).  rt_scene_create accepts leaves of any size and trees of up to 32 levels. */
 int rt_bvh_build_sah_binning(const void* prims, uint32_t nPrims, rt_bvh** out);
 void rt_bvh_destroy(rt_bvh* bvh);
 /* BVHInterface::nodes() / primitives() / numLevels() / numLeaves() (src/bvh_interface.h:64-71).

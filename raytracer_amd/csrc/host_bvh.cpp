@@ -280,10 +280,6 @@ struct Flattener {
         }
         if (n.data[0] & kLeafBit) {
             const uint32_t off = n.data[0] & ~kLeafBit, cnt = n.data[1];
-            if (cnt > kMaxLeafCount) {
-                snprintf(msg, msgLen, "flatten: leaf %u holds %u primitives (limit %u)", i, cnt, kMaxLeafCount);
-                return fail(RT_ERR_LIMIT);
-            }
             if (uint64_t(off) + cnt > nPrims || (cnt && !prims)) {
                 snprintf(msg, msgLen, "flatten: leaf %u range [%u,%u) exceeds %u primitives", i, off, off + cnt, nPrims);
                 return fail(RT_ERR_INVALID);
@@ -314,7 +310,11 @@ struct Flattener {
                 out.triEdges.push_back(ed);
                 out.triAttr.push_back(at);
             }
-            return kLeafBit | (cnt << kRefCountShift) | first;
+            if (cnt >= kMaxLeafCount) { // (the SAH-binned build leaves spans it cannot split cheaply whole: hundreds of triangles in one leaf)
+                if (out.leafCounts.empty()) out.leafCounts.assign(nPrims, 0u);
+                out.leafCounts[first] = cnt;
+            }
+            return kLeafBit | (std::min(cnt, kMaxLeafCount) << kRefCountShift) | first;
         }
         const uint32_t l = n.data[0], r = n.data[1];
         if (l >= nNodes || r >= nNodes) {
@@ -756,7 +756,9 @@ int rt_selftest_query_tree_built(const void* nodes, uint32_t nNodes, const void*
             lo = second ? p.lo1 : p.lo0, hi = second ? p.hi1 : p.hi0, ref = second ? p.ref1 : p.ref0;
         }
         if (!(ref & kLeafBit)) return fail("route does not end in a leaf");
-        const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+        const uint32_t first = ref & kRefOffsetMask;
+        uint32_t cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+        if (cnt == kMaxLeafCount && !flat.leafCounts.empty()) cnt = flat.leafCounts[first];
         if (c.compact < first || c.compact >= first + cnt) return fail("route ends in another leaf");
         if (memcmp(lo, c.leafLo, 12) || memcmp(hi, c.leafHi, 12)) return fail("leaf box differs");
     }

@@ -245,6 +245,14 @@ __device__ __forceinline__ bool box_test(const float lox, const float loy, const
     return true;
 }
 
+// Size of the leaf a reference names: the count field, or for the caller's leaves of 63 triangles and more the table entry.
+__device__ __forceinline__ uint32_t leaf_count(const SceneView& S, const uint32_t ref)
+{
+    uint32_t cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+    if (cnt == kMaxLeafCount && S.leafCounts) cnt = S.leafCounts[ref & kRefOffsetMask];
+    return cnt;
+}
+
 struct TraceCounters {
     uint32_t nodePairs, triTests, overflow;
     uint32_t node4; // 4-wide nodes of the library's query tree
@@ -685,7 +693,7 @@ __device__ __forceinline__ void trace(const SceneView& S, const bool useBvh, con
                 }
             }
             if (cur == kTraversalDone) break;
-            const uint32_t first = cur & kRefOffsetMask, cnt = (cur >> kRefCountShift) & kMaxLeafCount;
+            const uint32_t first = cur & kRefOffsetMask, cnt = leaf_count(S, cur);
             leaf_test_narrow<COUNT>(S, first, cnt, o, d, t, tri, tc);
             if (sp == 0) break;
             sp--;
@@ -1719,7 +1727,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
-        + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded((nTris / 32 + 1) * 4) + padded(nMaterials * sizeof(GpuMaterial))
+        + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(flat.leafCounts.size() * 4) + padded((nTris / 32 + 1) * 4) + padded(nMaterials * sizeof(GpuMaterial))
         + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQNodes * sizeof(Node4)) + padded(nQPairs * sizeof(NodePair))
         + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert))
         + padded(nQuadNodes * sizeof(QuadNode)) + padded(nQuadLeaves * sizeof(QuadLeaf)) + 256;
@@ -1730,6 +1738,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     TriEdges* hEdges = carve<TriEdges>(hp, nTris);
     TriAttr* hAttr = carve<TriAttr>(hp, nTris);
     uint32_t* hBrute = carve<uint32_t>(hp, nTris);
+    uint32_t* hLeafCounts = carve<uint32_t>(hp, flat.leafCounts.size());
     uint32_t* hReflects = carve<uint32_t>(hp, nTris / 32 + 1);
     GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
     GpuLight* hLight = carve<GpuLight>(hp, nLights);
@@ -1756,6 +1765,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         memcpy(hEdges, flat.triEdges.data(), nTris * sizeof(TriEdges));
         memcpy(hAttr, flat.triAttr.data(), nTris * sizeof(TriAttr));
         memcpy(hBrute, flat.bruteOrder.data(), nTris * 4);
+        if (!flat.leafCounts.empty()) memcpy(hLeafCounts, flat.leafCounts.data(), flat.leafCounts.size() * 4);
         for (size_t i = 0; i < nTris; i++) { // the material test of renderRay (src/recursive.cpp:62-80), once per triangle
             const float* m = materials8 + 8 * (size_t)flat.triAttr[i].meshID;
             if (m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f) hReflects[i >> 5] |= 1u << (i & 31);
@@ -1794,6 +1804,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     V.triEdges = carve<TriEdges>(dp, nTris);
     V.triAttr = carve<TriAttr>(dp, nTris);
     V.bruteOrder = carve<uint32_t>(dp, nTris);
+    V.leafCounts = carve<uint32_t>(dp, flat.leafCounts.size());
+    if (flat.leafCounts.empty()) V.leafCounts = nullptr;
     V.triReflects = carve<uint32_t>(dp, nTris / 32 + 1);
     V.materials = carve<GpuMaterial>(dp, nMaterials);
     V.lights = carve<GpuLight>(dp, nLights);

@@ -28,7 +28,7 @@ constexpr uint32_t kLeafBit = 1u << 31;
 //                    inner = index of the NodePair holding that node's two children
 constexpr uint32_t kRefCountShift = 25;
 constexpr uint32_t kRefOffsetMask = (1u << kRefCountShift) - 1;
-constexpr uint32_t kMaxLeafCount = 63;
+constexpr uint32_t kMaxLeafCount = 63; // the count field's largest value; in the caller's tree it stands for "63 or more: see leafCounts"
 constexpr int kStackDepth = 32; // per-lane traversal stack entries (LDS)
 
 // Two sibling 32-byte child records {box, ref, pad} = one 64-byte, 64-byte-aligned fetch per
@@ -140,6 +140,7 @@ struct SceneView {
     uint32_t rootRef;
     uint32_t nPairs, nTris, nMaterials, nLights, nSpheres;
     const TriCert* cert; // null in the reference-order view; per query-tree triangle otherwise
+    const uint32_t* leafCounts; // caller's tree: leafCounts[first triangle] = size of a leaf whose count field reads kMaxLeafCount (null: no such leaf)
     const Node4* nodes4; // query view: the query tree with four children per node, root = node 0 (`pairs` holds its binary form)
     const QuadNode* quadNodes; // query view: the same nodes, one record per child (null when a leaf holds more than four triangles)
     const QuadLeaf* quadLeaves;
@@ -155,6 +156,7 @@ struct FlatScene {
     std::vector<TriEdges> triEdges;
     std::vector<TriAttr> triAttr;
     std::vector<uint32_t> bruteOrder;
+    std::vector<uint32_t> leafCounts; // empty, or one entry per compact triangle: the size of the leaf that starts there, for leaves of 63 or more
     float rootLo[3], rootHi[3];
     uint32_t rootRef = 0;
     uint32_t maxDepth = 0;

@@ -408,7 +408,7 @@ __device__ __forceinline__ bool trace_wave_step(const SceneView& S, const bool h
         || __popcll(__ballot(parked)) >= kLeafBatch;
     if (test) {
         if (parked) {
-            const uint32_t first = T.pend & kRefOffsetMask, cnt = (T.pend >> kRefCountShift) & kMaxLeafCount;
+            const uint32_t first = T.pend & kRefOffsetMask, cnt = QUERY ? (T.pend >> kRefCountShift) & kMaxLeafCount : leaf_count(S, T.pend);
             leaf_test_narrow<COUNT, QUERY && !ANY>(S, first, cnt, T.R.o, T.R.d, T.t, T.tri, tc, &T.tieT);
             T.pend = 0;
             if (ANY && T.t < T.tieT) T.cur = kTraversalDone, T.sp = 0; // (tieT holds any_occluded(D) here) an occluder: the answer is settled
@@ -1690,7 +1690,7 @@ __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T
     if (active && j < n) {
         const int e = T.lq - 1 - j;
         const uint32_t ref = lq[e], key = QUERY ? 1u : lq[Lay::kLeafQ + e];
-        const uint32_t first = ref & kRefOffsetMask, cnt = (ref >> kRefCountShift) & kMaxLeafCount;
+        const uint32_t first = ref & kRefOffsetMask, cnt = QUERY ? (ref >> kRefCountShift) & kMaxLeafCount : leaf_count(S, ref);
         float tl = T.cullT; // the closest hit any lane of the group holds: nothing beyond it can win (equal distances stay in)
         uint32_t tril = kNoHit;
         // query-tree launches: one triangle in flight at a time keeps the kernel free of register spills at 4 waves per SIMD

@@ -2,7 +2,7 @@
 discontinuous in - a glossy sample rejected or kept on `dot(direction, normal) <= 0` (src/extra.cpp:497), a pixel inside or
 outside the bloom's threshold (src/extra.cpp:330-416) - where the GPU's sinf / cosf / powf differ from glibc's in the last ulp?
 
-    python tests/fuzz_diagnose.py <seed>... [feature=value ...]     (overrides applied to every seed's features)
+    python tests/fuzz_diagnose.py [big|soup] <seed>... [feature=value ...]     (overrides applied to every seed's features)
 """
 import sys
 
@@ -14,8 +14,9 @@ from fuzz_parity import O, api
 
 def main():
     override = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
-    for seed in [int(a) for a in sys.argv[1:] if "=" not in a]:
-        c = F.draw_case(seed)
+    mode = [a for a in sys.argv[1:] if a in ("big", "soup")]
+    for seed in [int(a) for a in sys.argv[1:] if a.isdigit()]:
+        c = F.draw_case(seed, "big" in mode, "soup" in mode)
         c["features"].update(override)
         c["frames"] = min(c["frames"], 2)
         print(F.describe(c))

@@ -2,10 +2,11 @@
 feature combinations, frame sizes, start depths and flags drawn from a seed; every case is held to the bar of
 test_gpu_parity.py.  Used by test_gpu_fuzz.py (a fixed set of seeds) and from the command line for longer runs:
 
-    python tests/fuzz_parity.py <first seed> <count> [big]   ->  one line per case, failures at the end (exit status 1)
+    python tests/fuzz_parity.py <first seed> <count> [big|soup]   ->  one line per case, failures at the end (exit status 1)
 
 `big`: frames of 1280x720 and 1920x1080 on the large scenes, up to four per call - the sizes at which the library changes its
-schedule (one ray per lane, hand-over, large-sequence settings).
+schedule (one ray per lane, hand-over, large-sequence settings).  `soup`: a generated scene per seed, triangles on a coarse grid
+with duplicates - exact ties of distance, rays through shared edges and vertices.
 """
 import os
 import sys
@@ -22,7 +23,50 @@ SCENES = ["cornell", "cornell_plight", "cube", "monkey", "teapot", "spheres", "k
 _cache = {}
 
 
+def soup(seed):
+    """A scene made to produce exact ties: triangles with vertices on a coarse grid (shared edges and vertices, coplanar and
+    crossing faces), some of them stored twice under different meshes (two hits at one distance: the reference reports the one
+    its walk tests last), lights and look-at points on the same grid, a sphere or two."""
+    r = np.random.default_rng(1_000_003 * seed + 17)
+    n = int(r.choice([1, 2, 5, 12, 40, 150, 400]))
+    step = float(r.choice([0.125, 0.25, 0.5]))
+    cells = int(round(1.0 / step))
+    pos = np.zeros((0, 3, 3), np.float32)
+    while len(pos) < n:
+        v = (r.integers(-cells, cells + 1, size=(2 * n + 8, 3, 3)) * step).astype(np.float32)
+        e1, e2 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+        area2 = np.cross(e1, e2)
+        keep = (np.abs(area2).sum(axis=1) > 0) & (np.abs(e1).max(axis=1) <= 4 * step) & (np.abs(e2).max(axis=1) <= 4 * step)
+        pos = np.concatenate([pos, v[keep]])[:n]
+    dup = r.random(n) < 0.15
+    pos = np.concatenate([pos, pos[dup]])
+    n_all = len(pos)
+    n_mesh = int(r.integers(1, 5))
+    ids = r.integers(0, n_mesh, n_all).astype(np.uint32)
+    geo = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]).astype(np.float32)
+    geo = geo / np.sqrt((geo * geo).sum(axis=1, dtype=np.float32))[:, None]
+    nrm = np.repeat(geo[:, None, :], 3, axis=1).astype(np.float32)
+    bend = r.random(n_all) < 0.5  # vertex normals that differ from the face's
+    nrm[bend] = nrm[bend] + r.uniform(-0.3, 0.3, (int(bend.sum()), 3, 3)).astype(np.float32)
+    uv = r.uniform(0, 1, (n_all, 3, 2)).astype(np.float32)
+    mats = np.zeros((n_mesh, 9), np.float32)
+    mats[:, 0:3] = r.uniform(0.1, 1.0, (n_mesh, 3))
+    mats[:, 3:6] = r.uniform(0.0, 0.9, (n_mesh, 3)) * (r.random((n_mesh, 1)) < 0.7)
+    mats[:, 6] = r.choice([1.0, 5.0, 20.0, 80.0], n_mesh)
+    mats[:, 7] = 1.0
+    lights = np.stack([scenes.point_light((r.integers(-2 * cells, 2 * cells + 1, 3) * step).astype(np.float32), r.uniform(0.3, 1.0, 3))
+                       for _ in range(int(r.integers(1, 3)))])
+    spheres = np.zeros((int(r.integers(0, 3)), 12), np.float32)
+    for sp in spheres:
+        sp[0:3] = r.integers(-cells, cells + 1, 3) * step
+        sp[3] = float(r.choice([step, 2 * step, 0.3]))
+        sp[4:7], sp[7:10], sp[10], sp[11] = r.uniform(0.1, 1, 3), r.uniform(0, 0.8, 3), 10.0, 1.0
+    return dict(prims=scenes.pack_prims(ids, pos, nrm, uv), materials=mats, lights=lights, spheres=spheres)
+
+
 def scene_arrays(name):
+    if name.startswith("soup:"):
+        return soup(int(name[5:]))
     if name == "knot":
         return scenes.dragon_standin(n_u=120, n_v=24)
     if name == "dragon":
@@ -42,16 +86,22 @@ def scene_pair(name, sah, transparent):
         if transparent:
             mats[::2, 7] = 0.6  # every other mesh lets 60 % through
             mats[1::3, 7] = 0.25
+        try:
+            o = O.OracleScene(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=sah)
+        except RuntimeError:  # input the reference's SAH-binned build is undefined on (centroids that coincide): the median build
+            sah = False
+            o = O.OracleScene(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"))
         g = api.Scene.from_triangles(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=sah)
-        o = O.OracleScene(sc["prims"], mats, sc["lights"], sc["spheres"], sc.get("textures"), sah_binning=sah)
         _cache[key] = (g, o)
     return _cache[key]
 
 
-def draw_case(seed, big=False):
+def draw_case(seed, big=False, soups=False):
     r = np.random.default_rng(seed)
     c = dict(seed=seed)
     c["scene"] = SCENES[r.integers(len(SCENES))]
+    if soups:
+        c["scene"] = f"soup:{seed}"
     c["sah"] = bool(r.random() < 0.3) and c["scene"] != "spheres"
     c["W"], c["H"] = int(r.integers(48, 200)), int(r.integers(32, 140))
     if big:
@@ -83,6 +133,12 @@ def draw_case(seed, big=False):
     c["flags"] = int(r.choice([0, 0, 0, api.RT_RENDER_NO_CULL, api.RT_RENDER_REFERENCE_TREE, api.RT_RENDER_SERIAL,
                                api.RT_RENDER_NO_CULL | api.RT_RENDER_REFERENCE_TREE]))
     c["frames"] = int(r.choice([1, 1, 1, 2, 5]))  # more than one: rt_render_images, one camera per frame
+    if soups:  # views along the grid's axes and diagonals, from grid points: rays through shared edges and vertices
+        c["frames"] = 1
+        c["cam"]["rot_deg"] = (float(r.choice([0.0, 45.0, 90.0, -90.0, 30.0])), float(r.choice([0.0, 45.0, 90.0, 180.0, -135.0])), 0.0)
+        c["cam"]["look_at"] = tuple(float(x) for x in r.integers(-2, 3, 3) * 0.25)
+        c["cam"]["dist"] = float(r.choice([0.5, 1.0, 2.0, 4.0]))
+        c["W"], c["H"] = int(r.choice([32, 64, 65, 128])), int(r.choice([32, 64, 63, 96]))
     if big:
         c["frames"] = int(r.choice([1, 1, 2, 4]))
         c["cam"]["dist"] = float(r.choice([0.4, 1.2, 3.0]))
@@ -162,9 +218,10 @@ def describe(c):
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    soups = len(sys.argv) > 3 and sys.argv[3] == "soup"
     failures = []
     for seed in range(first, first + count):
-        c = draw_case(seed, big)
+        c = draw_case(seed, big, soups)
         if big:
             print("     " + describe(c), flush=True)  # (a full-size oracle frame can take a minute)
         try:

@@ -213,6 +213,21 @@ def test_query_tree_is_a_sound_index_of_the_reference_tree(rt, name, sah_binning
         assert (rpairs, rdepth) == (32767, 16)
 
 
+def test_caller_trees_with_leaves_of_hundreds_of_triangles_are_accepted(rt):
+    """The SAH-binned build leaves a span it cannot split cheaply whole; on overlapping triangles that is most of the scene in one
+    leaf.  The flattened tree and the library's index of it must hold up (a leaf reference's count field ends at 63)."""
+    import fuzz_parity as F
+    sc = F.soup(0)
+    b = rt.Bvh(sc["prims"], sah_binning=True)
+    nodes = b.nodes()
+    assert int(nodes[(nodes[:, 6] >> 31) == 1][:, 7].max()) > 63
+    info = (C.c_uint32 * 8)()
+    rc = rt.lib().rt_selftest_query_tree(nodes.ctypes.data_as(C.c_void_p), b.num_nodes, b.primitives().ctypes.data_as(C.c_void_p),
+                                         b.num_primitives, len(sc["materials"]), info)
+    assert rc == rt.RT_OK, rt.lib().rt_last_error().decode()
+    assert info[0] == 1 and info[1] == len(sc["prims"])
+
+
 def test_query_tree_is_not_used_for_unnested_boxes(rt):
     """A caller's tree whose child boxes stick out of their parents' cannot carry the proof: the library must say so."""
     prims, mats, _, _ = O.load_scene_arrays("monkey")
