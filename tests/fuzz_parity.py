@@ -40,11 +40,16 @@ def soup(seed):
         pos = np.concatenate([pos, v[keep]])[:n]
     dup = r.random(n) < 0.15
     pos = np.concatenate([pos, pos[dup]])
+    if r.random() < 0.3:  # a few triangles without area (two corners in one place, or three on a line): they can never be hit
+        flat = r.random(len(pos)) < 0.1
+        pos[flat, 2] = np.where(r.random((int(flat.sum()), 1)) < 0.5, pos[flat, 1], 2 * pos[flat, 1] - pos[flat, 0])
     n_all = len(pos)
     n_mesh = int(r.integers(1, 5))
     ids = r.integers(0, n_mesh, n_all).astype(np.uint32)
     geo = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]).astype(np.float32)
-    geo = geo / np.sqrt((geo * geo).sum(axis=1, dtype=np.float32))[:, None]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        geo = geo / np.sqrt((geo * geo).sum(axis=1, dtype=np.float32))[:, None]
+    geo[~np.isfinite(geo).all(axis=1)] = (0.0, 1.0, 0.0)  # (vertex normals of the triangles without area)
     nrm = np.repeat(geo[:, None, :], 3, axis=1).astype(np.float32)
     bend = r.random(n_all) < 0.5  # vertex normals that differ from the face's
     nrm[bend] = nrm[bend] + r.uniform(-0.3, 0.3, (int(bend.sum()), 3, 3)).astype(np.float32)
