@@ -29,7 +29,11 @@ def main():
             kw = dict(c["cam"])
             kw["rot_deg"] = (kw["rot_deg"][0], kw["rot_deg"][1] + 37.0 * k, 0.0)
             cg, co = api.camera_from_trackball(W, H, **kw), O.make_camera(W, H, **kw)
-            ro = o.render(co, fo, W, H, start_depth=c["start_depth"])
+            O.lib().orc_set_shadow_walk_cap(c.get("walk_cap", 0))  # (a case with light through transparent surfaces bounds the walk on both sides)
+            try:
+                ro = o.render(co, fo, W, H, start_depth=c["start_depth"])
+            finally:
+                O.lib().orc_set_shadow_walk_cap(0)
             rays_o = (ro["stats"]["primary"], ro["stats"]["shadow"], ro["stats"]["secondary"])
             frames = {}
             for name, flags in (("as drawn", c["flags"]), ("depth-first", api.RT_RENDER_SERIAL), ("caller's tree", api.RT_RENDER_REFERENCE_TREE)):

@@ -53,20 +53,39 @@ def soup(seed):
     nrm = np.repeat(geo[:, None, :], 3, axis=1).astype(np.float32)
     bend = r.random(n_all) < 0.5  # vertex normals that differ from the face's
     nrm[bend] = nrm[bend] + r.uniform(-0.3, 0.3, (int(bend.sum()), 3, 3)).astype(np.float32)
-    uv = r.uniform(0, 1, (n_all, 3, 2)).astype(np.float32)
+    uv = r.uniform(-0.5, 1.5, (n_all, 3, 2)).astype(np.float32)  # also outside the image
     mats = np.zeros((n_mesh, 9), np.float32)
     mats[:, 0:3] = r.uniform(0.1, 1.0, (n_mesh, 3))
     mats[:, 3:6] = r.uniform(0.0, 0.9, (n_mesh, 3)) * (r.random((n_mesh, 1)) < 0.7)
     mats[:, 6] = r.choice([1.0, 5.0, 20.0, 80.0], n_mesh)
     mats[:, 7] = 1.0
-    lights = np.stack([scenes.point_light((r.integers(-2 * cells, 2 * cells + 1, 3) * step).astype(np.float32), r.uniform(0.3, 1.0, 3))
-                       for _ in range(int(r.integers(1, 3)))])
+    def light():
+        # near grid points, not on them: a light in the plane of a triangle makes every point of it a coin toss between lit and unlit
+        # (dot(normal, to the light) is 0 up to rounding), which a last-ulp difference in a glossy ray's hit point then flips
+        at = lambda: (r.integers(-2 * cells, 2 * cells + 1, 3) * step + r.uniform(0.01, 0.04, 3) * r.choice([-1.0, 1.0], 3)).astype(np.float32)
+        kind = int(r.choice([0, 0, 1, 2]))
+        rec = np.zeros(22, np.float32)
+        rec[0] = kind
+        if kind == 0:    # point: position, colour
+            rec[1:4], rec[4:7] = at(), r.uniform(0.3, 1.0, 3)
+        elif kind == 1:  # segment: two end points, their colours (src/common.h:50-53)
+            rec[1:4], rec[4:7], rec[7:10], rec[10:13] = at(), at(), r.uniform(0.2, 1.0, 3), r.uniform(0.2, 1.0, 3)
+        else:            # parallelogram: corner, two edges, four colours (src/common.h:55-60)
+            rec[1:4], rec[4:7], rec[7:10] = at(), r.integers(-2, 3, 3) * step, r.integers(-2, 3, 3) * step
+            rec[10:22] = r.uniform(0.0, 1.0, 12)
+        return rec
+    lights = np.stack([light() for _ in range(int(r.integers(1, 3)))])
     spheres = np.zeros((int(r.integers(0, 3)), 12), np.float32)
     for sp in spheres:
         sp[0:3] = r.integers(-cells, cells + 1, 3) * step
         sp[3] = float(r.choice([step, 2 * step, 0.3]))
         sp[4:7], sp[7:10], sp[10], sp[11] = r.uniform(0.1, 1, 3), r.uniform(0, 0.8, 3), 10.0, 1.0
-    return dict(prims=scenes.pack_prims(ids, pos, nrm, uv), materials=mats, lights=lights, spheres=spheres)
+    textures = {}
+    for m in range(n_mesh):
+        if r.random() < 0.5:  # Material::kdTexture: a small random image, odd sizes included
+            mats[m, 8] = 1.0
+            textures[m] = r.uniform(0.0, 1.0, (int(r.choice([1, 3, 8])), int(r.choice([2, 5, 8])), 3)).astype(np.float32)
+    return dict(prims=scenes.pack_prims(ids, pos, nrm, uv), materials=mats, lights=lights, spheres=spheres, textures=textures)
 
 
 def scene_arrays(name):
@@ -140,6 +159,11 @@ def draw_case(seed, big=False, soups=False):
     c["frames"] = int(r.choice([1, 1, 1, 2, 5]))  # more than one: rt_render_images, one camera per frame
     if soups:  # views along the grid's axes and diagonals, from grid points: rays through shared edges and vertices
         c["frames"] = 1
+        if c["transparent"] and r.random() < 0.5:  # light through transparent surfaces, the walk bounded at 64 surfaces on both sides
+            f["enableShadows"], c["walk_cap"] = 1, 64
+            if f.get("numGlossySamples", 1) > 2:  # (up to 64 queries per light sample and hit: keep the oracle's frame within seconds)
+                f["numGlossySamples"] = 2
+            f.pop("numPixelSamples", None), f.pop("enableJitteredSampling", None)
         c["cam"]["rot_deg"] = (float(r.choice([0.0, 45.0, 90.0, -90.0, 30.0])), float(r.choice([0.0, 45.0, 90.0, 180.0, -135.0])), 0.0)
         c["cam"]["look_at"] = tuple(float(x) for x in r.integers(-2, 3, 3) * 0.25)
         c["cam"]["dist"] = float(r.choice([0.5, 1.0, 2.0, 4.0]))
@@ -173,7 +197,11 @@ def run_case(c):
         cams.append((api.camera_from_trackball(W, H, **kw), O.make_camera(W, H, **kw)))
 
     def want_of(co):
-        ro = o.render(co, fo, W, H, start_depth=c["start_depth"])
+        O.lib().orc_set_shadow_walk_cap(c.get("walk_cap", 0))
+        try:
+            ro = o.render(co, fo, W, H, start_depth=c["start_depth"])
+        finally:
+            O.lib().orc_set_shadow_walk_cap(0)
         rgb = ro["rgb"]
         if f.get("enableBloomEffect"):
             rgb = O.bloom(rgb, f["bloomFilterSize"], f["bloomFilterThreshold"], f["bloomFilterIntensity"])
@@ -195,7 +223,10 @@ def run_case(c):
             print(f"note seed {c['seed']}: {id_bad} primary ids, {t_bad} distances of {n} differ", flush=True)
         got = (rg["stats"].primaryRays, rg["stats"].shadowRays, rg["stats"].secondaryRays)
         exp = (ro["stats"]["primary"], ro["stats"]["shadow"], ro["stats"]["secondary"])
-        if any(abs(a - b) > max(1, 1e-4 * b) for a, b in zip(got, exp)):
+        # (a walk through transparent occluders ends when it meets the shaded surface within 1e-5, src/light.cpp:107-136, and otherwise goes on
+        # to the bound: at grazing incidence that is decided by rounding, and each flip is worth up to 64 queries - 1e-3 on their count)
+        slack = (1e-4, 1e-3 if c.get("walk_cap") else 1e-4, 1e-4)
+        if any(abs(a - b) > max(1, k * b) for a, b, k in zip(got, exp, slack)):
             bad.append(f"ray counts {got} against {exp}")
         if rg["stats"].stackOverflows:
             bad.append("stack overflows")
@@ -227,8 +258,8 @@ def main():
     failures = []
     for seed in range(first, first + count):
         c = draw_case(seed, big, soups)
-        if big:
-            print("     " + describe(c), flush=True)  # (a full-size oracle frame can take a minute)
+        if big or c.get("walk_cap"):
+            print("     " + describe(c), flush=True)  # (the oracle's frame can take a minute)
         try:
             bad = run_case(c)
         except Exception as e:  # an error return is a finding too
