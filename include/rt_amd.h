@@ -174,6 +174,12 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
                     const float* materials8, uint32_t nMaterials, const float* lights22, uint32_t nLights,
                     const float* spheres12, uint32_t nSpheres, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
+/* Releases what the scene has allocated for rendering - the working buffers of every stream frames were queued on (about
+ * 3 KB per pixel of the largest launch sequence each), the frame buffers of rt_render_image(s) - after waiting for the
+ * device; the scene itself stays uploaded and the next render allocates again.  No counterpart in the reference (a
+ * Scene there owns no render state); for callers that keep many scenes alive on one GPU.  Counters of frames not yet
+ * fetched with rt_sync are lost. */
+int rt_scene_trim(rt_scene* scene);
 
 /* Material::kdTexture of mesh `material` (framework/include/framework/mesh.h:33): width*height RGB floats with the
  * rows as decoded, top row first - Image::pixels (framework/src/image.cpp:33-55), i.e. `&image.pixels[0].x`.

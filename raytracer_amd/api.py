@@ -110,6 +110,7 @@ def lib():
     L.rt_scene_create.argtypes = [vp, C.c_uint32, vp, C.c_uint32, u32p, f32p, C.c_uint32, f32p, C.c_uint32, f32p, C.c_uint32,
                                   C.POINTER(vp)]
     L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_trim.argtypes = [vp]
     L.rt_scene_set_texture.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_int]
     L.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.POINTER(Region), C.c_uint32,
                             vp, vp, vp, vp]
@@ -243,6 +244,10 @@ class Scene:
         if getattr(self, "h", None) and _lib is not None:
             _lib.rt_scene_destroy(self.h)
             self.h = None
+
+    def trim(self):
+        """rt_scene_trim: give back the scene's working buffers (the next render allocates them again)."""
+        check(lib().rt_scene_trim(self.h))
 
     def render_image(self, cam, features, W, H, start_depth=0, flags=0, want_ids=True):
         """rt_render_image: the reference's renderImage, host buffers in and out."""

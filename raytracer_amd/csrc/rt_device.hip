@@ -163,6 +163,7 @@ static int collect_frame(rt_scene* scene, struct Workspace& w, rt_stats* stats);
         hipError_t e_ = (call);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             rt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* reported here: a later launch check must not find it again */   \
             return RT_ERR_HIP;                                                                     \
         }                                                                                          \
     } while (0)
@@ -1905,6 +1906,26 @@ int rt_scene_set_texture(rt_scene* scene, uint32_t material, const float* rgb, i
     }
     (void)hipFree(scene->texturePixels[material]);
     scene->texturePixels[material] = d_px;
+    return RT_OK;
+}
+
+int rt_scene_trim(rt_scene* s)
+{
+    if (!s) {
+        rt::set_error("rt_scene_trim: null scene");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipDeviceSynchronize()); // nothing of this scene may still be running
+    for (Workspace* w : s->workspaces) free_workspace(w);
+    s->workspaces.clear();
+    for (rt_scene::ImageLane& l : s->imageLanes) {
+        (void)hipFree(l.d_rgb), (void)hipFree(l.d_scratch);
+        if (l.h_stage) (void)hipHostFree(l.h_stage);
+        l.d_rgb = l.d_scratch = l.h_stage = nullptr, l.frames = l.px = 0;
+    }
+    (void)hipFree(s->d_rgb), (void)hipFree(s->d_scratch), (void)hipFree(s->d_primId), (void)hipFree(s->d_primT);
+    s->d_rgb = s->d_scratch = nullptr, s->d_primId = nullptr, s->d_primT = nullptr, s->fbPixels = 0;
     return RT_OK;
 }
 

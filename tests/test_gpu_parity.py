@@ -838,6 +838,27 @@ def test_camera_sweep_frame_at_4k(rot_y):
     assert np.array_equal(acc.cpu().numpy().view(np.uint32), rg["rgb"].view(np.uint32))
 
 
+def test_trimming_a_scene_gives_its_working_buffers_back():
+    """rt_scene_trim: the buffers of the streams a scene rendered on are released (gigabytes at 1080p), and the next frames are
+    the same frames."""
+    import torch
+    g, _, _ = scene_pair("knot")
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=3, enableBloomEffect=1)
+    cams = [api.camera_from_trackball(640, 360, rot_deg=(20.0, 20.0 + 40.0 * k, 0.0)) for k in range(6)]
+    a = g.render_images(cams, fg, 640, 360, start_depth=2)
+    one = g.render_image(cams[1], fg, 640, 360, start_depth=2)
+    held = torch.cuda.mem_get_info()[0]
+    g.trim()
+    freed = torch.cuda.mem_get_info()[0] - held
+    print(f"trim released {freed / 2**20:.0f} MiB")
+    assert freed > 200 * 2**20
+    b = g.render_images(cams, fg, 640, 360, start_depth=2)
+    assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    assert np.array_equal(one["rgb"].view(np.uint32), g.render_image(cams[1], fg, 640, 360, start_depth=2)["rgb"].view(np.uint32))
+    assert a["stats"].rays == b["stats"].rays
+    assert api.lib().rt_scene_trim(None) == api.RT_ERR_INVALID
+
+
 def test_cpp_host_interface_renders_the_same_frame(tmp_path):
     """raytracer_amd/host (BVH / Trackball / Screen / renderImage in the reference's shapes) against the Python
     route to the same C ABI and against the oracle, on the example program's procedural scene."""
