@@ -176,9 +176,9 @@ def draw_case(seed, big=False, soups=False):
             f["numGlossySamples"] = 4
         if c["flags"] & api.RT_RENDER_SERIAL:
             c["flags"] = 0
-        # a camera inside the model makes every ray hit: keep a pixel's recursion tree near 100 rays, the oracle's frame within a minute
+        # a camera inside the model makes every ray hit: keep a pixel's recursion tree within a few dozen rays, the oracle's frame within a minute
         n = f.get("numGlossySamples", 1) if f.get("enableGlossyReflection") else 1
-        c["start_depth"] = max(c["start_depth"], {3: 2, 4: 3}.get(n, 0))
+        c["start_depth"] = max(c["start_depth"], {2: 2, 3: 3, 4: 4}.get(n, 0))
         if n >= 3:
             c["frames"] = min(c["frames"], 2)
     return c
