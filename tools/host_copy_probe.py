@@ -14,7 +14,10 @@ print("cpu copy pinned -> pageable: %.2f ms per 25 MB frame" % ((time.perf_count
 rt = torch.cuda.cudart()
 for rep in range(2):
     t0 = time.perf_counter()
-    for d in dst: assert int(rt.cudaHostRegister(d.ctypes.data, d.nbytes, 0)) == 0
+    if any(int(rt.cudaHostRegister(d.ctypes.data, d.nbytes, 0)) != 0 for d in dst[:1]):
+        print("hipHostRegister refuses this memory on this box (measured: it does): only the staged copy is available")
+        break
+    for d in dst[1:]: assert int(rt.cudaHostRegister(d.ctypes.data, d.nbytes, 0)) == 0
     t1 = time.perf_counter()
     for d in dst:
         t = torch.from_numpy(d)
