@@ -178,12 +178,16 @@ constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere inde
 constexpr uint32_t kTraversalDone = 0xffffffffu;
 constexpr uint64_t kMaxQueueTasks = 1ull << 29; // per queue
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
-constexpr uint32_t kMaxTraceLaunches = 6 * kMaxRounds + 1024; // work counters for the trace launches of one frame
+constexpr uint32_t kTraceSlotsPerRound = 8; // counters one stage's launches take at most: hand-over list, fall-back list, up to six launches (second pass included)
+constexpr uint32_t kMaxTraceLaunches = kTraceSlotsPerRound * kMaxRounds + 1024; // work counters for the trace launches of one frame
 constexpr uint64_t kMaxShadowRays = 1ull << 26;  // shadow rays in flight per chunk of shade tasks
 constexpr uint32_t kMaxShadowSegments = 64;      // surfaces a light sample is followed through (transparent shadows)
 constexpr uint32_t kMaxBatchRays = 16;           // candidate rays of a batched glossy loop (numGlossySamples <= 5)
 
 enum StatSlot { S_PRIMARY = 0, S_SHADOW, S_SECONDARY, S_NODEPAIRS, S_TRITESTS, S_PIXELS, S_OVERFLOW, S_DROPPED, S_BIGVALUE, S_NODE4, S_COUNT = 10 };
+// Words of the FIRST copy beyond the counters: what the earlier frames of a launch sequence that is rendered frame by frame leave
+// for rt_sync (carry_frame_counts_kernel) - the most shade / leaf tasks one of them appended, and their fall-back queries.
+enum CarrySlot { S_QMAX_SHADE = 10, S_QMAX_LEAF = 11, S_FALL_SUM = 12 };
 // The counters exist kStatCopies times, 256 B apart; a workgroup adds to the copy of its index and rt_sync sums them.
 // (Additions to one address are served one at a time, about 9 ns each: 8,000 waves ending together would wait 70 us.)
 constexpr uint32_t kStatCopies = 64, kStatStride = 32; // stride in counters
@@ -213,6 +217,59 @@ __device__ __forceinline__ float sampler_next(uint32_t& state)
     v *= 277803737u;
     v ^= v >> 22u;
     return static_cast<float>(v) / 4294967295.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sin / cos of a glossy sample's angle (sampleDisk, src/extra.cpp:443-450: glm::cos / glm::sin of a float = the host
+// libm's cosf / sinf).  A sample is kept or rejected on the sign of dot(direction, normal) (src/extra.cpp:491-499), and
+// from a rejection on the pixel's sampler sequence is another: the last bit of these two values decides ray COUNTS, so
+// they are computed as the reference's libm (glibc 2.35, sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h,
+// s_sincosf_data.c) computes them: in double, one multiply-subtract range reduction to [-pi/4, pi/4] with the quadrant
+// from a scaled float-to-int conversion, then the sine or cosine polynomial of the quadrant, rounded to float once.
+// Bit-identical to that libm's sinf / cosf for every float in [0, 2 pi] (all 1,086,918,685 of them were compared on
+// the host, with and without fused multiply-adds: the double results never lie close enough to a rounding boundary
+// for the contraction to matter); the angle of a sample lies in that interval.  Arguments of 120 and beyond, which the
+// libm reduces with a table this function does not carry, are answered by the device's own sinf / cosf.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void libm_sincosf(const float y, float& sn, float& cs)
+{
+    constexpr double kHpiInv = 0x1.45F306DC9C883p+23; // 2 / pi * 2^24
+    constexpr double kHpi = 0x1.921FB54442D18p0;      // pi / 2
+    constexpr double kC0 = 0x1p0, kC1 = -0x1.ffffffd0c621cp-2, kC2 = 0x1.55553e1068f19p-5, kC3 = -0x1.6c087e89a359dp-10,
+                     kC4 = 0x1.99343027bf8c3p-16;
+    constexpr double kS1 = -0x1.555545995a603p-3, kS2 = 0x1.1107605230bc4p-7, kS3 = -0x1.994eb3774cf24p-13;
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu; // exponent and the first mantissa bits of |y|
+    if (!(top < 0x42fu)) { // |y| >= 120, infinities, NaN: not an angle of sampleDisk
+        sn = sinf(y), cs = cosf(y);
+        return;
+    }
+    double x = (double)y;
+    int n = 0;
+    double sign = 1.0;
+    bool flip = false; // quadrants 2 and 3: the cosine polynomial changes sign
+    if (top < 0x3f4u) { // |y| < pi / 4 (as a float: 0x1.921FB6p-1f)
+        if (top < 0x398u) { // |y| < 2^-12
+            sn = y, cs = 1.0f;
+            return;
+        }
+    } else {
+        const double r = x * kHpiInv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * kHpi;
+        sign = (n & 3) == 1 || (n & 3) == 2 ? -1.0 : 1.0; // sign of the sine in the quadrant: {1, -1, -1, 1}
+        flip = (n & 2) != 0;
+    }
+    const double x2 = x * x;
+    // the sine polynomial takes x * sign, the cosine polynomial x; both take x * x
+    const double xs = x * sign;
+    const double x3 = xs * x2, s1 = kS2 + x2 * kS3, x7 = x3 * x2, s = xs + x3 * kS1;
+    const float sinPoly = (float)(s + x7 * s1);
+    const double c0 = flip ? -kC0 : kC0, c1 = flip ? -kC1 : kC1, c2 = flip ? -kC2 : kC2, c3 = flip ? -kC3 : kC3, c4 = flip ? -kC4 : kC4;
+    const double x4 = x2 * x2, cc2 = c3 + x2 * c4, cc1 = c0 + x2 * c1, x6 = x4 * x2, c = cc1 + x4 * c2;
+    const float cosPoly = (float)(c + x6 * cc2);
+    // sinf evaluates the polynomial of quadrant n, cosf that of quadrant n ^ 1: odd quadrants swap the two
+    sn = (n & 1) ? cosPoly : sinPoly;
+    cs = (n & 1) ? sinPoly : cosPoly;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1253,7 +1310,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderParams P)
                     const float r = radius * sqrtf(sampler_next(smp));
                     const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
                     float sn, cs;
-                    sincosf(angle, &sn, &cs);
+                    libm_sincosf(angle, sn, cs);
                     const float dx = r * cs, dy = r * sn;
                     const vec3 pd = normalize(w + dx * u + dy * v);
                     lightSample++;
@@ -1566,6 +1623,16 @@ uint64_t binomial(uint32_t n, uint32_t k)
     for (uint32_t i = 1; i <= k_min; i++) coef = (coef * (n - i + 1)) / i;
     return coef;
 }
+// Between two frames of a launch sequence that is rendered frame by frame (keepStats): the next frame zeroes the queue
+// counters and the launch counters, so what rt_sync needs of the frame just rendered moves into the statistics block.
+__global__ void carry_frame_counts_kernel(const uint32_t* qCount, const uint32_t* fallCount, unsigned long long* stats)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if ((unsigned long long)qCount[0] > stats[S_QMAX_SHADE]) stats[S_QMAX_SHADE] = qCount[0];
+    if ((unsigned long long)qCount[1] > stats[S_QMAX_LEAF]) stats[S_QMAX_LEAF] = qCount[1];
+    if (fallCount) stats[S_FALL_SUM] += *fallCount;
+}
+
 void gaussian_taps(uint32_t F, float* taps)
 {
     const uint32_t radius = F * 2 + 1;
@@ -1977,6 +2044,10 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         rt::set_error("rt_render_frames: %d frames of %d rows exceed 65535 rows per launch sequence", nFrames, height);
         return RT_ERR_LIMIT;
     }
+    if (!(flags & RT_RENDER_SERIAL) && (width > 65535 || height > 65535)) { // ... and x in the other 16 (the depth-first kernel packs nothing)
+        rt::set_error("rt_render: a frame of %dx%d pixels exceeds 65535 columns or rows - use RT_RENDER_SERIAL", width, height);
+        return RT_ERR_LIMIT;
+    }
     int rc = check_features(features);
     if (rc != RT_OK) return rc;
     rt_region reg { 8, 0, 1 };
@@ -2001,6 +2072,11 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     const int myTileRows = myStripes * stripeTileRows;
     const uint32_t nWork = (uint32_t)nFrames * (uint32_t)myTileRows * (uint32_t)tilesX * 64u;
     if (!keepStats) RT_HIP(hipMemsetAsync(w.d_stats, 0, kStatCopies * kStatStride * sizeof(unsigned long long), st));
+    else if (w.lastWasWavefront) { // the frame before this one of the sequence: its queue and fall-back counters are about to be zeroed
+        // (schedules that render frame by frame leave at most one fall-back counter: the persistent launch's)
+        const uint32_t* fall = (w.fallSlots.size() == 1 && w.d_roundCounts) ? w.d_roundCounts + w.fallSlots[0] : nullptr;
+        hipLaunchKernelGGL(carry_frame_counts_kernel, dim3(1), dim3(64), 0, st, w.d_work + 8, fall, w.d_stats);
+    }
     RT_HIP(hipMemsetAsync(w.d_work, 0, 256, st));
     w.lastWasWavefront = false;
     if (nWork == 0) return RT_OK;
@@ -2238,7 +2314,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
     if (features->enableTransparency) chain = transparentChain;
     if (usePath) chain = 0; // no rounds: a pixel's chain may be as long as it likes
-    if (chain > kMaxRounds - 1 || 6 * nChunks + 32 > kMaxTraceLaunches - 6 * kMaxRounds) {
+    if (chain > kMaxRounds - 1 || kTraceSlotsPerRound * nChunks + 32 > kMaxTraceLaunches - kTraceSlotsPerRound * kMaxRounds) {
         rt::set_error("rt_render: a full recursion tree needs %llu sequential rays per pixel (limit %u) and %u shadow chunks - "
                       "use RT_RENDER_SERIAL",
                       (unsigned long long)chain, kMaxRounds - 1, nChunks);
@@ -2723,11 +2799,13 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
 {
     (void)scene;
     unsigned long long h[S_COUNT] = {};
+    unsigned long long carried[3] = {}; // S_QMAX_SHADE, S_QMAX_LEAF, S_FALL_SUM: earlier frames of a sequence rendered frame by frame
     {
         unsigned long long all[kStatCopies * kStatStride];
         RT_HIP(hipMemcpy(all, w.d_stats, sizeof(all), hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < kStatCopies; c++)
             for (int i = 0; i < S_COUNT; i++) h[i] += all[c * kStatStride + i];
+        for (int i = 0; i < 3; i++) carried[i] = all[S_COUNT + i];
     }
 #ifdef RT_PATH_PROFILE
     {
@@ -2776,6 +2854,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             RT_HIP(hipMemcpy(c.data(), w.d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (uint32_t slot : w.fallSlots) stats->referenceTreeQueries += c[slot - lo];
         }
+        stats->referenceTreeQueries += carried[S_FALL_SUM - S_COUNT]; // earlier frames of a sequence rendered frame by frame
     }
     if (h[S_OVERFLOW]) {
         rt::set_error("traversal stack overflowed %llu times: results are incomplete", h[S_OVERFLOW]);
@@ -2784,6 +2863,9 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     if (w.lastWasWavefront) { // did every deferred task fit its queue?  The counters keep counting past the capacity.
         uint32_t q[2];
         RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
+        // (a sequence rendered frame by frame: the fullest queues any of its frames had)
+        q[0] = (uint32_t)std::max<unsigned long long>(q[0], carried[S_QMAX_SHADE - S_COUNT]);
+        q[1] = (uint32_t)std::max<unsigned long long>(q[1], carried[S_QMAX_LEAF - S_COUNT]);
         if (q[0] > w.shadeCap || q[1] > w.leafCap) {
             // the next frame gets queues of the size this one asked for and a quarter more
             const bool canGrow = (q[0] > w.shadeCap && w.shadeCap < kMaxQueueTasks) || (q[1] > w.leafCap && w.leafCap < kMaxQueueTasks);
@@ -2946,6 +3028,7 @@ int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, con
     // (more streams with shorter sequences before fewer with longer ones: 4 x 5 frames render faster than 2 x 8)
     int lanes = (int)std::max<size_t>(1, std::min<size_t>(std::min(nFrames, 4), kFlightPixels / px));
     int perSequence = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, kSequencePixels / px), kFlightPixels / ((size_t)lanes * px)));
+    perSequence = std::min(perSequence, std::max(1, 65535 / height)); // rows of a launch sequence (rt_render_frames)
     perSequence = std::min(perSequence, (nFrames + lanes - 1) / lanes);
     lanes = std::min(lanes, (nFrames + perSequence - 1) / perSequence);
     for (int k = 0; k < lanes; k++) {

@@ -962,7 +962,7 @@ __device__ __forceinline__ bool glossy_sample(uint32_t& smp, const float radius,
     const float r = radius * sqrtf(sampler_next(smp));
     const float angle = sampler_next(smp) * 2 * 3.14159265358979323846264338327950288f;
     float sn, cs;
-    sincosf(angle, &sn, &cs);
+    libm_sincosf(angle, sn, cs);
     const float dx = r * cs, dy = r * sn;
     pd = normalize(w + dx * u + dy * v);
     return !(dot(pd, nrm) <= 0);
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                     const float r = radius * sqrtf(sampler_next(L.smp));
                     const float angle = sampler_next(L.smp) * 2 * 3.14159265358979323846264338327950288f;
                     float sn, cs;
-                    sincosf(angle, &sn, &cs);
+                    libm_sincosf(angle, sn, cs);
                     const float dx = r * cs, dy = r * sn;
                     const vec3 pd = normalize(w + dx * u + dy * v);
                     i++;

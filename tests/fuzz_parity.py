@@ -225,8 +225,10 @@ def run_case(c):
         exp = (ro["stats"]["primary"], ro["stats"]["shadow"], ro["stats"]["secondary"])
         # (a walk through transparent occluders ends when it meets the shaded surface within 1e-5, src/light.cpp:107-136, and otherwise goes on
         # to the bound: at grazing incidence that is decided by rounding, and each flip is worth up to 64 queries - 1e-3 on their count)
-        slack = (1e-4, 1e-3 if c.get("walk_cap") else 1e-4, 1e-4)
-        if any(abs(a - b) > max(1, k * b) for a, b, k in zip(got, exp, slack)):
+        # Everything else that decides a ray count is integer work or correctly rounded arithmetic (the glossy sample's sin / cos are
+        # evaluated as the host libm evaluates them): the counts are equal.
+        slack = (0.0, 1e-3 if c.get("walk_cap") else 0.0, 0.0)
+        if any(abs(a - b) > k * b for a, b, k in zip(got, exp, slack)):
             bad.append(f"ray counts {got} against {exp}")
         if rg["stats"].stackOverflows:
             bad.append("stack overflows")
@@ -252,11 +254,19 @@ def describe(c):
 
 
 def main():
-    first, count = int(sys.argv[1]), int(sys.argv[2])
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"
-    soups = len(sys.argv) > 3 and sys.argv[3] == "soup"
+    """usage: fuzz_parity.py FIRST COUNT [big|soup]   or   fuzz_parity.py seeds [plain|big|soup]:S1,S2,... ..."""
+    cases = []
+    if sys.argv[1] == "seeds":
+        for group in sys.argv[2:]:
+            mode, _, seeds = group.partition(":")
+            cases += [(int(x), mode == "big", mode == "soup") for x in seeds.split(",") if x]
+    else:
+        first, count = int(sys.argv[1]), int(sys.argv[2])
+        mode = sys.argv[3] if len(sys.argv) > 3 else ""
+        cases = [(seed, mode == "big", mode == "soup") for seed in range(first, first + count)]
+    count = len(cases)
     failures = []
-    for seed in range(first, first + count):
+    for seed, big, soups in cases:
         c = draw_case(seed, big, soups)
         if big or c.get("walk_cap"):
             print("     " + describe(c), flush=True)  # (the oracle's frame can take a minute)
