@@ -160,10 +160,12 @@ def main():
     torch.cuda.set_device(device_index)
     api.check(api.lib().rt_set_device(device_index))
     if world > 1:
+        import datetime
+        patience = datetime.timedelta(seconds=300)  # a collective a rank never joins ends the job with an error instead of hanging it
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=patience)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
     dev = torch.device("cuda", device_index)
 
     wl = WORKLOADS[args.workload]
@@ -244,12 +246,16 @@ def main():
         sizes += [K] * (rest // K) + ([rest % K] if rest % K else [])
         return [(sum(sizes[:i]), c) for i, c in enumerate(sizes)]
 
-    def run(i, first, count, ev=None, fl=None):
-        """Launch sequence i = frames [first, first + count): queued on stream i % F; nothing waits on the host."""
+    step_of = (lambda j: rank + j * world) if by_frames else (lambda j: j)  # which step of the job this rank's j-th frame is
+
+    def run(i, first, count, ev=None, fl=None, cam_list=None, host_dst=None):
+        """Launch sequence i = frames [first, first + count): queued on stream i % F; nothing waits on the host.  ev: four events
+        recorded on the sequence's stream - before the render, after it, after the stripe exchange, after bloom + copy."""
         k = i % F
         st = streams[k]
-        step_of = (lambda j: rank + j * world) if by_frames else (lambda j: j)  # which step of the job this rank's j-th frame is
-        seq_cams = [cams[step_of(first + f) % len(cams)] for f in range(count)] if cams else [cam] * count
+        src = cam_list if cam_list is not None else cams
+        seq_cams = [src[step_of(first + f) % len(src)] for f in range(count)] if src else [cam] * count
+        dst = host[k] if host_dst is None else host_dst
         last_count[k] = count
         with torch.cuda.stream(st):
             if ev:
@@ -267,43 +273,58 @@ def main():
                     cpu = frames[k][:count].cpu()
                     mine = plans[k].assemble(cpu, dist)
                     frames[k][:count].copy_(cpu)
+            if ev:
+                ev[2].record(st)
             if feat.enableBloomEffect:
                 for f in mine:
                     api.bloom_device(frames[k][f].data_ptr(), scratch[k].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
                                      feat.bloomFilterIntensity, stream=st.cuda_stream)
             if whole:
-                host[k][:count].copy_(frames[k][:count], non_blocking=True)
+                dst[:count].copy_(frames[k][:count], non_blocking=True)
             else:
                 for f in mine:
-                    host[k][f].copy_(frames[k][f], non_blocking=True)
+                    dst[f].copy_(frames[k][f], non_blocking=True)
+            if ev:
+                ev[3].record(st)
+        return list(mine)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not a step: every stream's frame buffers are allocated by its first sequence, and frames whose deferred tasks
-    # overflow the default queue sizes (many glossy samples) make the scene allocate larger ones for the frames after them
-    for attempt in range(4):
-        for i in range(F):
-            run(i, i * K, K)
-        barrier()
-        again = False
-        for k in range(F):
-            try:
-                scene.sync(streams[k].cuda_stream)
-            except api.RtError as e:
-                if e.code != api.RT_ERR_AGAIN:
-                    raise
-                again = True
-        if world > 1:  # a rank whose queues have grown renders its set-up sequences again: all ranks go along (the exchanges pair up)
-            flag = torch.tensor([1.0 if again else 0.0], dtype=torch.float64)
-            if args.backend == "nccl":
-                flag = flag.to(dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            again = bool(flag.item() > 0)
-        if not again:
-            break
+    def fail(msg):  # a bench line over incomplete or wrong frames is worse than none
+        print(f"bench.py rank {rank}: {msg}", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)
+
+    def settle(cam_list=None):
+        """Set-up, not a step: one sequence per stream, repeated while a frame's deferred tasks overflow the scene's queues
+        (rt_sync: RT_ERR_AGAIN - the next render allocates what the frame asked for).  The first pass also allocates
+        every stream's buffers."""
+        for attempt in range(5):
+            for i in range(F):
+                run(i, i * K, K, cam_list=cam_list)
+            barrier()
+            again = False
+            for k in range(F):
+                try:
+                    scene.sync(streams[k].cuda_stream)
+                except api.RtError as e:
+                    if e.code != api.RT_ERR_AGAIN:
+                        raise
+                    again = True
+            if world > 1:  # a rank whose queues have grown renders its set-up sequences again: all ranks go along (the exchanges pair up)
+                flag = torch.tensor([1.0 if again else 0.0], dtype=torch.float64)
+                if args.backend == "nccl":
+                    flag = flag.to(dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                again = bool(flag.item() > 0)
+            if not again:
+                return
+        fail("the scene's task queues still grow after five set-up passes")
+
+    settle()
     for i, (first, count) in enumerate(sequences(my_warmup)):
         run(i, first, count)
     barrier()
@@ -315,19 +336,56 @@ def main():
         if sum(sizes) != my_steps or max(sizes) > K or min(sizes) < 1:
             raise SystemExit(f"--sequence-sizes must add up to {my_steps} steps, each within 1..{K}")
         timed = [(sum(sizes[:i]), n) for i, n in enumerate(sizes)]
-    timed_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
-    t0 = time.perf_counter()
-    for i, (first, count) in enumerate(timed):
-        run(i, first, count, timed_ev[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launch_ms_timed = float(np.mean([a.elapsed_time(b) for a, b in timed_ev]))  # one launch sequence among the others in flight
+    ranks_seen = [0]
+    if world > 1:
+        # Every rank must queue the same sequences (their exchanges pair up): a rank that disagrees would leave the others
+        # waiting in a collective for ever.  Compared here, before anything is timed; a difference ends every rank at once.
+        mine_desc = torch.full((66,), -1.0, dtype=torch.float64)
+        mine_desc[0], mine_desc[1] = float(K), float(F)
+        for j, (_, n) in enumerate(timed[:64]):
+            mine_desc[2 + j] = float(n)
+        if args.backend == "nccl":
+            mine_desc = mine_desc.to(dev)
+        all_desc = [torch.empty_like(mine_desc) for _ in range(world)]
+        dist.all_gather(all_desc, mine_desc)
+        ranks_seen = list(range(len(all_desc)))
+        if dist.get_world_size() != world or any(not torch.equal(d, all_desc[0]) for d in all_desc):
+            fail("the ranks do not agree on the launch sequences of the timed region: " + "; ".join(str([int(x) for x in d.tolist() if x >= 0]) for d in all_desc))
+
+    def timed_region(seqs, cam_list=None):
+        """The steps as launch sequences queued back to back on the F streams, between two barriers.  Every sequence copies
+        its finished frames into a pinned host buffer of its own (within 6 GB in all; beyond that the streams' buffers are
+        reused and only each stream's last sequence can be looked at afterwards).  After the second barrier, outside the timed
+        region, every stream is asked for its status (rt_sync): a sequence that overflowed a queue ends the run."""
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in seqs]
+        own = sum(n for _, n in seqs) * H * W * 12 <= (6 << 30)
+        hosts = [torch.empty((n, H, W, 3), dtype=torch.float32, pin_memory=True) if own else host[i % F] for i, (_, n) in enumerate(seqs)]
+        done = []
+        barrier()
+        t0 = time.perf_counter()
+        for i, (first, count) in enumerate(seqs):
+            done.append(run(i, first, count, evs[i], cam_list=cam_list, host_dst=hosts[i] if own else None))
+        barrier()
+        dt = time.perf_counter() - t0
+        for k in range(min(F, len(seqs))):
+            try:
+                scene.sync(streams[k].cuda_stream)
+            except api.RtError as e:
+                fail(f"a timed launch sequence on stream {k} is incomplete: {e}")
+        keep = range(len(seqs)) if own else range(max(0, len(seqs) - F), len(seqs))
+        return dt, evs, {i: (seqs[i][0], done[i], hosts[i]) for i in keep}
+
+    elapsed, timed_ev, timed_frames = timed_region(timed)
+    launch_ms_timed = float(np.mean([e[0].elapsed_time(e[1]) for e in timed_ev]))  # one launch sequence among the others in flight
+    stage_ms = [float(np.mean([e[a].elapsed_time(e[a + 1]) for e in timed_ev])) for a in range(3)]  # render, exchange, bloom + copy
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    device_mem_gb = (total_b - free_b) / 1e9
 
     # one frame with nothing else queued: its latency, and the duration of the rt_render launch sequence by itself
     # (events on the stream the launches run on)
     alone, kernel_ms = [], []
     for i in range(6):
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         run(0, i, 1, ev, flags)
@@ -335,6 +393,68 @@ def main():
         alone.append((time.perf_counter() - t1) * 1e3)
         kernel_ms.append(ev[0].elapsed_time(ev[1]))
     alone_ms, kernel_ms = float(np.median(alone[1:])), float(np.median(kernel_ms[1:]))
+
+    # Every timed frame against the same camera's frame rendered ALONE - whole, by one rt_render with nothing else queued,
+    # then rt_bloom - bit for bit, outside the timed region.  A frame that differs ends the run.
+    ref_dev = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    ref_cache = {}
+
+    def reference_frame(c, key):
+        if key not in ref_cache:
+            for attempt in range(4):
+                scene.render_device(c, feat, W, H, wl["start_depth"], ref_dev.data_ptr(), flags=flags, stream=streams[0].cuda_stream)
+                try:
+                    st_ref = scene.sync(streams[0].cuda_stream)
+                    break
+                except api.RtError as e:
+                    if e.code != api.RT_ERR_AGAIN or attempt == 3:
+                        fail(f"the frame rendered alone is incomplete: {e}")
+            if feat.enableBloomEffect:
+                api.bloom_device(ref_dev.data_ptr(), scratch[0].data_ptr(), W, H, feat.bloomFilterSize, feat.bloomFilterThreshold,
+                                 feat.bloomFilterIntensity, stream=streams[0].cuda_stream)
+            streams[0].synchronize()
+            if len(ref_cache) >= 2:
+                ref_cache.clear()
+            ref_cache[key] = (ref_dev.cpu().view(torch.int32), st_ref)
+        return ref_cache[key]
+
+    def verify(kept, cam_list):
+        n_ok, rays = 0, 0
+        for i, (first, done, hbuf) in sorted(kept.items()):
+            for f in done:
+                step = step_of(first + f)
+                c, key = (cam_list[step % len(cam_list)], step % len(cam_list)) if cam_list else (cam, -1)
+                ref, st_ref = reference_frame(c, key)
+                if not torch.equal(hbuf[f].view(torch.int32), ref):
+                    bad = int((hbuf[f].view(torch.int32) != ref).sum().item())
+                    fail(f"timed frame {step} (sequence {i}) differs from the frame rendered alone in {bad} values")
+                n_ok += 1
+                rays += st_ref.rays
+        return n_ok, rays
+
+    verified, _ = verify(timed_frames, cams)
+    del timed_frames
+
+    # The same steps from distinct cameras on an orbit (rotation.y = 20 + 360 k / steps degrees), as the reference's loop over the
+    # configuration's cameras renders them (src/main.cpp:515-526) - a second figure beside the headline, whose steps all look
+    # through the metric configuration's one camera.
+    orbit = None
+    if world == 1 and not cams and args.steps > 1:
+        ocams = [api.camera_from_trackball(W, H, rot_deg=(20.0, 20.0 + 360.0 * k / args.steps, 0.0)) for k in range(args.steps)]
+        settle(ocams)  # other views fill the queues differently
+        o_dt, _, o_frames = timed_region(timed, ocams)
+        o_ok, o_rays = verify(o_frames, ocams)
+        del o_frames
+        if o_ok == args.steps:
+            orbit = {"cameras": args.steps, "ms_per_step": o_dt / args.steps * 1e3, "value": o_rays / o_dt / 1e6, "unit": "Mrays/s",
+                     "rays_per_frame_mean": o_rays / args.steps, "frames_verified": o_ok,
+                     "note": "the same steps and sequences from distinct cameras, rotation.y = 20 + 360 k / steps degrees"}
+        else:
+            orbit = {"cameras": args.steps, "ms_per_step": o_dt / args.steps * 1e3, "frames_verified": o_ok,
+                     "note": "ray total not taken: not every frame's host copy was kept"}
+        settle()  # back to the metric configuration's camera for the counting passes below
+    ref_cache.clear()
+    del ref_dev
 
     s0 = streams[0].cuda_stream
     if cams:  # every frame of the sweep has its own ray count: recount them outside the timed region
@@ -347,6 +467,7 @@ def main():
         rays_rank = torch.tensor(tot, dtype=torch.float64)
     else:
         rays_rank = torch.tensor([stats.primaryRays, stats.shadowRays, stats.secondaryRays, stats.pixels], dtype=torch.float64) / stats_frames
+    elapsed_rank = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         if args.backend == "nccl":
@@ -360,8 +481,8 @@ def main():
 
     # Algorithmic bytes of rank 0's render launch (one rt_render = a fixed sequence of kernels on one stream, dominated by
     # the trace kernels), counted by a counting pass of the frame as it is scheduled and timed: 128 B per 4-wide node of
-    # the query tree, 64 B per node pair (group launches, rays traced again in the caller's tree), 48 B per triangle test
-    # (plane, then two edge records), 28 B ray in + 16 B hit out per ray, 12 B per pixel written.  Candidate rays that are
+    # the query tree, 64 B per node pair (group launches, rays traced again in the caller's tree), 36 B per triangle test,
+    # 28 B ray in + 16 B hit out per ray, 12 B per pixel written.  Candidate rays that are
     # discarded and rays traced twice are in the node and triangle counts.  The same figure for the reference's own walk,
     # which visits every box a ray enters (no culling, the caller's tree, 36 B per test), is reported beside it and is not
     # the basis of `achieved`.
@@ -372,8 +493,12 @@ def main():
         wk = scene.sync(s0)
         for name in ("queryNodeSteps", "nodePairSteps", "triangleTests", "primaryRays", "shadowRays", "secondaryRays", "pixels"):
             setattr(wk, name, getattr(wk, name) // n)
-        tri_b = 48.0 if schedule else 36.0
-        return wk, 128.0 * wk.queryNodeSteps + 64.0 * wk.nodePairSteps + tri_b * wk.triangleTests + 44.0 * wk.rays + 12.0 * wk.pixels
+        # a triangle test: 36 B, the nine floats of its positions, as the coverage contract prices it (the layout read here is a
+        # 16-byte plane record and, for candidates in range, an 80-byte edge record: 48 B with two edge reads in five tests -
+        # reported beside it as algorithmic_bytes_layout)
+        base = 128.0 * wk.queryNodeSteps + 64.0 * wk.nodePairSteps + 44.0 * wk.rays + 12.0 * wk.pixels
+        wk.layout_bytes = base + (48.0 if schedule else 36.0) * wk.triangleTests
+        return wk, base + 36.0 * wk.triangleTests
     try:
         work, alg_bytes = counted(flags_timed, True)
         counted_what = "one frame of a launch sequence as scheduled and timed (query tree, candidate batches, second traces)"
@@ -389,15 +514,20 @@ def main():
         ref_work, ref_bytes = counted(api.RT_RENDER_NO_CULL | api.RT_RENDER_SERIAL, False)
     achieved = alg_bytes * args.steps / elapsed / 1e9          # sustained over the timed region, frames in flight together
     achieved_alone = alg_bytes / (kernel_ms * 1e-3) / 1e9      # one launch sequence with the GPU to itself
-    traffic, traffic_note = None, None
+    traffic, traffic_note, limiter, per_kernel = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and world == 1:
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(args.workload)
             traffic_note = tj.get("_measured")
+            if traffic is not None:  # counters were taken on this workload: what they say bounds it, and the per-kernel table they come with
+                limiter, per_kernel = tj.get("_limiter"), tj.get("_per_kernel")
         except Exception:
             traffic = None
+    # HBM bytes per frame from the counters against the time a frame takes here: the fraction of the HBM roof the frame's real
+    # traffic amounts to (the algorithmic bytes are mostly served by the caches: the tree and the triangles are a few MB)
+    hbm_traffic_frac = traffic * args.steps / elapsed / 1e9 / HBM_PEAK_GBS if traffic else None
 
     # The same steps through the one blocking call a host program makes (rt_render_images: pageable images in and out, the library's
     # own streams and pinned staging) - reported beside the headline, never as `value`.  The scene's buffers of the runs above are
@@ -418,6 +548,18 @@ def main():
         except Exception as e:  # never at the expense of the line
             host_api = {"entry": "rt_render_images", "error": str(e)[:200]}
 
+    # what each rank's sequences spent where (events on their streams): render, stripe exchange, bloom + copy to the host
+    per_rank = None
+    if world > 1:
+        mine_ms = torch.tensor([float(rank)] + stage_ms + [elapsed_rank * 1e3], dtype=torch.float64)
+        if args.backend == "nccl":
+            mine_ms = mine_ms.to(dev)
+        all_ms = [torch.empty_like(mine_ms) for _ in range(world)]
+        dist.all_gather(all_ms, mine_ms)
+        per_rank = [{"rank": int(t[0].item()), "render_ms": float(t[1].item()), "exchange_ms": float(t[2].item()),
+                     "bloom_copy_ms": float(t[3].item()), "elapsed_ms": float(t[4].item())} for t in all_ms]
+    else:
+        per_rank = [{"rank": 0, "render_ms": stage_ms[0], "exchange_ms": stage_ms[1], "bloom_copy_ms": stage_ms[2], "elapsed_ms": elapsed_rank * 1e3}]
     out = None
     if rank == 0:
         out = {
@@ -434,26 +576,34 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "ms_per_frame_alone": alone_ms,
+            "orbit": orbit,
+            "verified": {"timed_frames_equal_to_frames_rendered_alone": verified, "of": my_steps, "timed_sequences_complete": True,
+                         "note": "after the timed region every stream's status was read with rt_sync and every timed frame kept in host "
+                                 "memory was compared bit for bit with the same camera's frame rendered alone; a difference ends the run"},
             "host_api": host_api,
+            "per_rank": {"ranks_seen": ranks_seen, "sequences": [n for _, n in timed], "stages_ms_per_sequence": per_rank,
+                         "note": "mean over a rank's timed launch sequences, events on the sequence's stream; sequences of different streams overlap"},
             "mrays_per_s_one_frame_alone": rays_frame / world / alone_ms / 1e3 if world == 1 else None,
             "config": {"workload": args.workload, "description": wl["desc"], "width": W, "height": H,
                        "triangles": int(len(sc["prims"])), "mesh_hash": _scenes.mesh_hash(sc), "mesh": args.obj or wl["scene"],
                        "rays_per_frame": int(rays_frame), "frames_per_sequence": K, "sequences_in_flight": F, "frames_in_flight": K * F,
-                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "device_mem_gb": round(device_mem_gb, 2),
                        "step": "one frame: its share of rt_render_frames" + (" + stripe all-to-all (frame f whole on rank f % N)" if world > 1 and not by_frames else "")
                                + " + rt_bloom + frame copy to pinned host memory",
                        "partition": (f"whole frames dealt to {world} GPUs in turn, no exchange" if by_frames else
                                      f"interleaved 8-row stripes over {world} GPU(s)" + (f", {args.backend} all-to-all" if world > 1 else "")),
                        "culling": not args.no_cull},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic": traffic, "traffic_source": traffic_note, "hbm_traffic_frac": hbm_traffic_frac, "limiter": limiter,
+                         "per_kernel": per_kernel,
                          "kernel": "launch sequence of rt_render_frames (camera, trace/group_trace per stage, path/leaf/shade logic, resolve)",
                          "note": "achieved = algorithmic bytes of one frame x steps / elapsed time of the timed region (sequences_in_flight "
                                  "launch sequences of frames_per_sequence frames share the GPU); launch_ms_timed = mean duration of one such "
                                  "sequence there, kernel_ms = the launch sequence of ONE frame alone (rt_render), both from events on the "
                                  "sequence's stream",
                          "launch_ms_timed": launch_ms_timed, "kernel_ms": kernel_ms, "achieved_one_launch_alone": achieved_alone,
-                         "algorithmic_bytes_per_launch": alg_bytes, "counted": counted_what,
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_layout": work.layout_bytes, "counted": counted_what,
+                         "bytes_per_unit": "128 B per 4-wide query node, 64 B per node pair, 36 B per triangle test, 28 B ray in + 16 B hit out, 12 B per pixel",
                          "query_nodes_per_ray": work.queryNodeSteps / max(work.rays, 1),
                          "node_pairs_per_ray": work.nodePairSteps / max(work.rays, 1), "tri_tests_per_ray": work.triangleTests / max(work.rays, 1),
                          "reference_walk": {"bytes_per_launch": ref_bytes,

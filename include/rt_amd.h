@@ -227,16 +227,21 @@ int rt_bloom(float* d_rgb, float* d_scratch, int width, int height, uint32_t fil
  * every GPU the library runs on, held until the process ends); the call allocates and frees nothing.  Frames of more
  * than RT_BLOOM_STATIC_MAX_PIXELS pixels are rejected with RT_ERR_LIMIT.  Every call on a GPU shares that GPU's array:
  * calls that overlap on one GPU (two streams, two threads) race; calls queued on one stream do not.  Results are
- * those of rt_bloom bit for bit. */
+ * those of rt_bloom bit for bit.  The GPU that owns `stream` must be the calling thread's current device (RT_ERR_INVALID
+ * otherwise).  The array's address on a GPU is looked up once, under a lock, by the first of rt_set_device, rt_scene_create
+ * or rt_bloom_static that runs with that GPU current: a caller under graph capture makes one of those calls beforehand. */
 #define RT_BLOOM_STATIC_MAX_PIXELS (1u << 21) /* 2,097,152: a 1920x1080 frame fits */
 int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, float threshold, float intensity,
                     void* stream);
 
 /* Wait for the work queued on `stream` by the calls above and fetch the ray counters of the last frame queued on that
  * stream (a scene keeps the buffers and counters of a frame per stream: see RT_RENDER_OVERLAPPED; a stream must not be
- * destroyed while the scene lives).  RT_ERR_LIMIT reports a frame that is incomplete: a queue of the default pipeline
- * overflowed, or a single contribution to a pixel reached 4e6 in magnitude, beyond the fixed-point pixel sums of the
- * default pipeline (RT_RENDER_SERIAL has neither limit; rt_render_image falls back to it by itself).  It also notes how many
+ * destroyed while the scene lives).  A frame that is incomplete is reported in one of two ways.  RT_ERR_AGAIN: a task queue
+ * of the default pipeline overflowed and can grow - the next rt_render of the scene allocates what the frame asked for:
+ * render the frame again.  RT_ERR_LIMIT: a queue overflowed at its largest size, or a single contribution to a pixel
+ * reached 4e6 in magnitude, beyond the fixed-point pixel sums of the default pipeline: render with RT_RENDER_SERIAL, which
+ * has neither limit (rt_render_image and rt_render_images do both by themselves).  A launch sequence that was rendered frame
+ * by frame is reported as a whole: incomplete if any of its frames is.  It also notes how many
  * rays each round of the frame held: the next rt_render of the same size, depth, flags, features and region leaves out
  * the launches that only serve larger rounds (a hint - the frame is the same whatever the plan says). */
 int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);

@@ -1481,6 +1481,25 @@ static __device__ __align__(256) float g_bloomScratch[3ull * RT_BLOOM_STATIC_MAX
 constexpr int kMaxDevices = 64;
 float* g_bloomScratchPtr[kMaxDevices] = {}; // device address of g_bloomScratch per device (hipGetSymbolAddress)
 std::mutex g_bloomScratchMutex;
+// The address of the current device's copy of the static bloom array, looked up on the first call per device (with that
+// device current) and kept.  rt_set_device and rt_scene_create call it too, so that a caller who has set up a scene on a GPU
+// finds the address resolved when it later calls rt_bloom_static from a place that must not take a lock or query the runtime.
+int bloom_static_scratch(const int device, float** out)
+{
+    if (device < 0 || device >= kMaxDevices) {
+        rt::set_error("rt_bloom_static: device %d outside [0,%d)", device, kMaxDevices);
+        return RT_ERR_LIMIT;
+    }
+    std::lock_guard<std::mutex> lock(g_bloomScratchMutex);
+    if (!g_bloomScratchPtr[device]) {
+        void* p = nullptr;
+        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_bloomScratch)));
+        g_bloomScratchPtr[device] = static_cast<float*>(p);
+    }
+    *out = g_bloomScratchPtr[device];
+    return RT_OK;
+}
+
 
 constexpr int kBloomRowTile = 256;
 // pass 1: threshold (applyThreshold, :186-196) + filter along x (applyFilter1dToPixel toRow, :307-314)
@@ -1750,7 +1769,8 @@ int rt_device_count(int* count)
 int rt_set_device(int device)
 {
     RT_HIP(hipSetDevice(device));
-    return RT_OK;
+    float* unused = nullptr;
+    return bloom_static_scratch(device, &unused); // (see there: resolved at set-up, for rt_bloom_static)
 }
 
 int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint32_t nPrims, const uint32_t* primIds,
@@ -1787,6 +1807,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         delete s;
         rt::set_error("rt_scene_create: no HIP device available");
         return RT_ERR_HIP;
+    }
+    {
+        float* unused = nullptr;
+        (void)bloom_static_scratch(s->device, &unused); // set-up on this device: rt_bloom_static finds its array's address resolved
     }
     QueryTree qt;
     // the library's own tree: hierarchy on the device unless RT_AMD_HOST_QUERY_BUILD asks for the host builder
@@ -2775,20 +2799,17 @@ int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, fl
     }
     int device = -1;
     RT_HIP(hipGetDevice(&device));
-    if (device < 0 || device >= kMaxDevices) {
-        rt::set_error("rt_bloom_static: device %d outside [0,%d)", device, kMaxDevices);
-        return RT_ERR_LIMIT;
+    if (stream) { // the array used is the one of the GPU the kernels will run on: that GPU must be the current one
+        hipDevice_t streamDevice = -1;
+        RT_HIP(hipStreamGetDevice(static_cast<hipStream_t>(stream), &streamDevice));
+        if ((int)streamDevice != device) {
+            rt::set_error("rt_bloom_static: the stream belongs to device %d, the current device is %d", (int)streamDevice, device);
+            return RT_ERR_INVALID;
+        }
     }
     float* scratch = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_bloomScratchMutex);
-        if (!g_bloomScratchPtr[device]) { // first call on this device, which is the current one
-            void* p = nullptr;
-            RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_bloomScratch)));
-            g_bloomScratchPtr[device] = static_cast<float*>(p);
-        }
-        scratch = g_bloomScratchPtr[device];
-    }
+    const int rc = bloom_static_scratch(device, &scratch);
+    if (rc != RT_OK) return rc;
     // pass 1 writes every pixel of the intermediate image that pass 2 reads: nothing of an earlier call is read
     return rt_bloom(d_rgb, scratch, width, height, filterSize, threshold, intensity, nullptr, stream);
 }

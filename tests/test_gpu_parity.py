@@ -424,6 +424,39 @@ def test_task_queues_grow_for_a_frame_that_overflows_them():
     assert np.array_equal(r2["rgb"].view(np.uint32), frame.cpu().numpy().view(np.uint32))
 
 
+def test_a_sequence_rendered_frame_by_frame_reports_an_overflow_of_any_of_its_frames():
+    """rt_render_frames with chains too long for rounds (glossy x16: a pixel per lane, the frames one after the other on the
+    stream): the first camera's frame overflows the task queues, the second's (far away, a few pixels of model) does not.
+    rt_sync must report the sequence incomplete with RT_ERR_AGAIN although the frame rendered last was complete, the queues
+    must grow, and the sequence rendered again must hold both cameras' frames."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.dragon_standin(n_u=120, n_v=24)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=16)
+    W, H = 128, 72
+    cams = [both_cameras(W, H, dist=2.0)[0], both_cameras(W, H, dist=60.0)[0]]
+    frames = torch.zeros((2, H, W, 3), dtype=torch.float32, device="cuda")
+    g.render_frames_device(cams, fg, W, H, 2, frames.data_ptr(), stream=0)
+    with pytest.raises(api.RtError) as e:
+        g.sync(0)
+    assert e.value.code == api.RT_ERR_AGAIN and "grow" in str(e.value)
+    for attempt in range(4):
+        g.render_frames_device(cams, fg, W, H, 2, frames.data_ptr(), stream=0)
+        try:
+            st = g.sync(0)
+            break
+        except api.RtError as again:
+            assert again.code == api.RT_ERR_AGAIN and attempt < 3
+    assert st.pipeline == api.RT_PIPELINE_PERSISTENT
+    rays = 0
+    got = frames.cpu().numpy()
+    for k, cam in enumerate(cams):
+        rs = g.render_image(cam, fg, W, H, start_depth=2, flags=api.RT_RENDER_SERIAL, want_ids=False)
+        assert np.abs(got[k] - rs["rgb"]).max() < 1e-5, k
+        rays += rs["stats"].rays
+    assert st.rays == rays and np.abs(got[1]).max() > 0  # the far frame sees the model
+
+
 def test_frames_on_several_streams_overlap_without_mixing():
     """Frames of one scene queued on different streams run on buffers of their own: five cameras on five streams at once
     (more streams than the scene keeps buffer sets, so one set is taken over) give the frames and ray counts of the same

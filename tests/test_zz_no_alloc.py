@@ -1,7 +1,6 @@
 """rt_bloom_static (the entry point that allocates nothing) against rt_bloom, through the C ABI, bit for bit: two calls
 in a row on one GPU, the second with a smaller frame, so that the static scratch array still holds the first call's
-rows when the second runs.  Also checked: the result equals the CPU oracle's, a frame beyond the array is rejected,
-and the array's address comes from the device the call runs on."""
+rows when the second runs.  Also checked: the result equals the CPU oracle's and a frame beyond the array is rejected."""
 import ctypes as C
 
 import numpy as np
