@@ -262,6 +262,35 @@ int rt_render_image(rt_scene* scene, const rt_camera* camera, const rt_features*
 int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, const rt_features* features, int width,
                      int height, int startDepth, uint32_t flags, float* const* rgb, rt_stats* stats);
 
+/* The same loop on several GPUs of one node, from one process: scenes[k] is the same scene resident on some GPU (rt_scene_clone
+ * puts a scene on another GPU; one scene object per participant, two of them may share a GPU).  Every frame is cut into
+ * stripes of 8 image rows, stripe s is rendered by participant s % nScenes (pixels are independent in the reference's loop,
+ * src/render.cpp:27-44, and a pixel's sampler seed depends on its own position only, src/render.cpp:38: nothing is exchanged
+ * while rendering); frame f of a launch sequence is completed on participant f % nScenes, which copies the other participants'
+ * stripes of it GPU to GPU, applies the bloom to the whole frame and hands it to the caller - every frame reaches host memory
+ * once, from one GPU.  One host thread per participant; the threads meet once per launch sequence, and the stripe copies of
+ * one sequence run while the next is rendered.  Images and counters are those of rt_render_images.  nScenes == 1 is
+ * rt_render_images. */
+int rt_render_images_multi(rt_scene* const* scenes, int nScenes, const rt_camera* cameras, int nFrames, const rt_features* features,
+                           int width, int height, int startDepth, uint32_t flags, float* const* rgb, rt_stats* stats);
+/* A copy of `scene` on GPU `device` (any visible GPU, also the one it is on): the uploaded arrays and textures are copied GPU
+ * to GPU; working buffers, streams and launch plans are the copy's own.  No counterpart in the reference (a Scene there lives in
+ * host memory that every thread shares); destroyed with rt_scene_destroy like any scene. */
+int rt_scene_clone(const rt_scene* scene, int device, rt_scene** out);
+/* The GPU a scene is resident on. */
+int rt_scene_device(const rt_scene* scene, int* device);
+/* One of the scene's own four streams (hipStream_t; created on first use, alive as long as the scene; the ones rt_render_images
+ * queues its launch sequences on - streams 0 and 1 at the device's higher stream priority).  For callers that want frames in
+ * flight without owning streams; do not use them while rt_render_images runs on the scene. */
+int rt_scene_stream(rt_scene* scene, int index, void** stream);
+/* The stripe partition, on the host (no GPU needed).  rt_stripe_owner: the participant that renders image row `imageRow`
+ * (row 0 is the bottom row of the picture, as in Screen::setPixel, src/screen.cpp:36-42).  rt_stripe_plan: the stripes of
+ * one participant as runs of memory rows of the Screen-order frame (memory row m holds image row height - 1 - m,
+ * src/screen.cpp:119-122): up to `capacity` entries into firstRows / rowCounts; returns the number of stripes (-1: bad
+ * arguments). */
+int rt_stripe_owner(int height, int imageRow, int participants);
+int rt_stripe_plan(int height, int participants, int participant, int* firstRows, int* rowCounts, int capacity);
+
 /* BVHInterface::intersect (src/bvh_interface.h:61) for a batch of rays on the GPU.
  * rays: HOST n x 7 floats {origin3, direction3, t}; t is updated in place.
  * hits: HOST n x 12 dwords {normal3, barycentric3, texCoord2 (floats), primId, meshID, hit(0/1), 0}. */

@@ -125,6 +125,13 @@ def lib():
                                   f32p, C.POINTER(Stats)]
     L.rt_render_images.argtypes = [vp, C.POINTER(Camera), C.c_int, C.POINTER(Features), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(f32p),
                                    C.POINTER(Stats)]
+    L.rt_render_images_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(Camera), C.c_int, C.POINTER(Features), C.c_int, C.c_int, C.c_int,
+                                         C.c_uint32, C.POINTER(f32p), C.POINTER(Stats)]
+    L.rt_scene_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rt_scene_device.argtypes = [vp, C.POINTER(C.c_int)]
+    L.rt_scene_stream.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rt_stripe_owner.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.rt_stripe_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.rt_intersect.argtypes = [vp, C.POINTER(Features), f32p, C.c_uint32, vp]
     L.rt_selftest_division.argtypes = [C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.rt_selftest_query_tree.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -267,6 +274,24 @@ class Scene:
         check(lib().rt_render_images(self.h, (Camera * len(cams))(*cams), len(cams), C.byref(features), W, H, start_depth, flags, ptrs, C.byref(st)))
         return dict(rgb=rgb, stats=st)
 
+    def clone(self, device=None):
+        """rt_scene_clone: the same scene once more, on GPU `device` (default: the one it is on)."""
+        if device is None:
+            device = self.device()
+        h = C.c_void_p()
+        check(lib().rt_scene_clone(self.h, device, C.byref(h)))
+        other = object.__new__(Scene)
+        other.h = h
+        for name in ("nodes", "prims", "prim_ids", "materials", "lights", "spheres", "bvh"):
+            if hasattr(self, name):
+                setattr(other, name, getattr(self, name))
+        return other
+
+    def device(self):
+        d = C.c_int()
+        check(lib().rt_scene_device(self.h, C.byref(d)))
+        return d.value
+
     def render_device(self, cam, features, W, H, start_depth, d_rgb, d_prim=None, d_t=None, region=None, flags=0, stream=None):
         """rt_render on caller-owned device memory (integers = device addresses). Asynchronous."""
         check(lib().rt_render(self.h, C.byref(cam), C.byref(features), W, H, start_depth, C.byref(region) if region else None, flags,
@@ -290,6 +315,27 @@ class Scene:
         return dict(t=rays[:, 6].copy(), normal=hits[:, 0:3].view(np.float32).copy(), bary=hits[:, 3:6].view(np.float32).copy(),
                     uv=hits[:, 6:8].view(np.float32).copy(), prim=hits[:, 8].copy(), mesh=hits[:, 9].copy(),
                     hit=hits[:, 10].astype(bool))
+
+
+def render_images_multi(scenes, cams, features, W, H, start_depth=0, flags=0):
+    """rt_render_images_multi: the loop over cameras on several participants (one Scene object each; Scene.clone makes them)."""
+    rgb = np.zeros((len(cams), H, W, 3), np.float32)
+    ptrs = (f32p * len(cams))(*[rgb[k].ctypes.data_as(f32p) for k in range(len(cams))])
+    handles = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    st = Stats()
+    check(lib().rt_render_images_multi(handles, len(scenes), (Camera * len(cams))(*cams), len(cams), C.byref(features), W, H, start_depth, flags,
+                                       ptrs, C.byref(st)))
+    return dict(rgb=rgb, stats=st)
+
+
+def stripe_plan(height, participants, participant):
+    """rt_stripe_plan: the (first memory row, rows) runs of one participant's stripes in a Screen-order frame."""
+    n = lib().rt_stripe_plan(height, participants, participant, None, None, 0)
+    if n < 0:
+        raise ValueError("bad stripe plan arguments")
+    first, rows = (C.c_int * max(n, 1))(), (C.c_int * max(n, 1))()
+    lib().rt_stripe_plan(height, participants, participant, first, rows, n)
+    return [(first[i], rows[i]) for i in range(n)]
 
 
 def bloom_device(d_rgb, d_scratch, W, H, F=15, threshold=0.5, intensity=0.8, region=None, stream=None):

@@ -2000,6 +2000,125 @@ int rt_scene_set_texture(rt_scene* scene, uint32_t material, const float* rgb, i
     return RT_OK;
 }
 
+int rt_scene_device(const rt_scene* scene, int* device)
+{
+    if (!scene || !device) {
+        rt::set_error("rt_scene_device: null argument");
+        return RT_ERR_INVALID;
+    }
+    *device = scene->device;
+    return RT_OK;
+}
+
+int rt_scene_stream(rt_scene* scene, int index, void** stream)
+{
+    if (!scene || !stream || index < 0 || index >= 4) {
+        rt::set_error("rt_scene_stream: null argument or index outside [0,4)");
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(scene->device));
+    rt_scene::ImageLane& l = scene->imageLanes[index];
+    if (!l.stream) {
+        // equal sequences on equal streams run in step, all asking for the same resource at a time: two of the four
+        // streams get the higher of the device's stream priorities and the sequences drift apart
+        int least = 0, greatest = 0;
+        RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        RT_HIP(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, index < 2 ? greatest : least));
+    }
+    *stream = l.stream;
+    return RT_OK;
+}
+
+// The scene once more, on another GPU (or the same): the uploaded arrays are copied device to device and every pointer into
+// them moved by the distance between the two copies; textures likewise.  Render state (working buffers, streams, launch
+// plan) is not shared: the copy starts without any.
+int rt_scene_clone(const rt_scene* src, int device, rt_scene** out)
+{
+    if (!src || !out) {
+        rt::set_error("rt_scene_clone: null argument");
+        return RT_ERR_INVALID;
+    }
+    *out = nullptr;
+    int count = 0;
+    RT_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        rt::set_error("rt_scene_clone: device %d outside [0,%d)", device, count);
+        return RT_ERR_INVALID;
+    }
+    int previous = 0;
+    RT_HIP(hipGetDevice(&previous));
+    rt_scene* s = new (std::nothrow) rt_scene(*src); // the knobs, tree depths, light types ... (and pointers that are replaced below)
+    if (!s) {
+        rt::set_error("rt_scene_clone: out of memory");
+        return RT_ERR_NOMEM;
+    }
+    s->device = device;
+    s->d_blob = nullptr, s->d_rgb = s->d_scratch = nullptr, s->d_primId = nullptr, s->d_primT = nullptr, s->fbPixels = 0;
+    for (rt_scene::ImageLane& l : s->imageLanes) l = rt_scene::ImageLane();
+    s->d_textures = nullptr;
+    s->texturePixels.assign(src->texturePixels.size(), nullptr);
+    s->retired.clear(), s->roundRays.clear(), s->planKey = 0;
+    s->workspaces.clear(), s->useCounter = 0;
+    auto fail = [&](const char* what, hipError_t e) {
+        rt::set_error("rt_scene_clone: %s failed: %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        rt_scene_destroy(s);
+        (void)hipSetDevice(previous);
+        return RT_ERR_HIP;
+    };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail("hipSetDevice", e);
+    {
+        float* unused = nullptr;
+        (void)bloom_static_scratch(device, &unused);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->numCUs = cus;
+    }
+    e = hipMalloc(&s->d_blob, src->blobBytes);
+    if (e == hipSuccess) e = hipMemcpyPeer(s->d_blob, device, src->d_blob, src->device, src->blobBytes);
+    if (e != hipSuccess) return fail("copying the scene's arrays", e);
+    const ptrdiff_t moved = static_cast<char*>(s->d_blob) - static_cast<char*>(src->d_blob);
+    auto move_view = [&](SceneView& V) {
+        auto mv = [&](auto*& p) {
+            using T = std::remove_reference_t<decltype(p)>;
+            if (p) p = reinterpret_cast<T>(reinterpret_cast<char*>(const_cast<void*>(static_cast<const void*>(p))) + moved);
+        };
+        mv(V.pairs), mv(V.triPlane), mv(V.triEdges), mv(V.triAttr), mv(V.bruteOrder), mv(V.leafCounts), mv(V.triReflects);
+        mv(V.materials), mv(V.lights), mv(V.spheres), mv(V.cert), mv(V.nodes4), mv(V.quadNodes), mv(V.quadLeaves), mv(V.refPairs);
+    };
+    move_view(s->view), move_view(s->queryView);
+    // textures: the table's entries point at allocations of their own
+    const size_t nMat = src->texturePixels.size();
+    std::vector<GpuTexture> table(nMat ? nMat : 1);
+    memset(table.data(), 0, table.size() * sizeof(GpuTexture));
+    e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), table.size() * sizeof(GpuTexture));
+    if (e != hipSuccess) return fail("hipMalloc of the texture table", e);
+    if (nMat) {
+        e = hipSetDevice(src->device);
+        if (e == hipSuccess) e = hipMemcpy(table.data(), src->d_textures, nMat * sizeof(GpuTexture), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipSetDevice(device);
+        if (e != hipSuccess) return fail("reading the texture table", e);
+        for (size_t m = 0; m < nMat; m++) {
+            if (!src->texturePixels[m]) {
+                memset(&table[m], 0, sizeof(GpuTexture));
+                continue;
+            }
+            const size_t bytes = (size_t)table[m].width * (size_t)table[m].height * 12;
+            e = hipMalloc(reinterpret_cast<void**>(&s->texturePixels[m]), bytes);
+            if (e == hipSuccess) e = hipMemcpyPeer(s->texturePixels[m], device, src->texturePixels[m], src->device, bytes);
+            if (e != hipSuccess) return fail("copying a texture", e);
+            table[m].pixels = s->texturePixels[m];
+        }
+    }
+    e = hipMemcpy(s->d_textures, table.data(), table.size() * sizeof(GpuTexture), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail("writing the texture table", e);
+    s->view.textures = s->d_textures, s->queryView.textures = s->d_textures;
+    (void)hipSetDevice(previous);
+    *out = s;
+    return RT_OK;
+}
+
 int rt_scene_trim(rt_scene* s)
 {
     if (!s) {
@@ -3054,13 +3173,9 @@ int rt_render_images(rt_scene* scene, const rt_camera* cameras, int nFrames, con
     lanes = std::min(lanes, (nFrames + perSequence - 1) / perSequence);
     for (int k = 0; k < lanes; k++) {
         rt_scene::ImageLane& l = scene->imageLanes[k];
-        if (!l.stream) {
-            // equal sequences on equal streams run in step, all asking for the same resource at a time: two of the four
-            // streams get the higher of the device's stream priorities and the sequences drift apart
-            int least = 0, greatest = 0;
-            RT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            RT_HIP(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, k < 2 ? greatest : least));
-        }
+        void* made = nullptr;
+        const int rcLane = rt_scene_stream(scene, k, &made);
+        if (rcLane != RT_OK) return rcLane;
         if (l.px * l.frames < px * perSequence || l.px < px) {
             RT_HIP(hipStreamSynchronize(l.stream));
             (void)hipFree(l.d_rgb), (void)hipFree(l.d_scratch);

@@ -111,7 +111,27 @@ BVH::BVH(const Scene& scene, const Features& features)
     }
     rt_bvh_destroy(h);
 }
-BVH::~BVH() { rt_scene_destroy(m_device); }
+BVH::~BVH()
+{
+    for (size_t k = 1; k < m_perGpu.size(); k++) rt_scene_destroy(m_perGpu[k]);
+    rt_scene_destroy(m_device);
+}
+
+std::span<rt_scene* const> BVH::deviceScenes(int gpus) const
+{
+    int visible = 1, home = 0;
+    check(rt_device_count(&visible), "rt_device_count");
+    check(rt_scene_device(m_device, &home), "rt_scene_device");
+    const int want = std::max(1, gpus <= 0 ? visible : std::min(gpus, visible));
+    if (m_perGpu.empty()) m_perGpu.push_back(m_device);
+    // participant k lives on GPU (home + k) % visible: the scene's own GPU first
+    while ((int)m_perGpu.size() < want) {
+        rt_scene* copy = nullptr;
+        check(rt_scene_clone(m_device, (home + (int)m_perGpu.size()) % visible, &copy), "rt_scene_clone");
+        m_perGpu.push_back(copy);
+    }
+    return std::span<rt_scene* const>(m_perGpu.data(), (size_t)want);
+}
 
 bool BVH::intersect(RenderState& state, Ray& ray, HitInfo& hitInfo) const
 {
@@ -204,7 +224,7 @@ rt_stats renderImage(const Scene& scene, const BVHInterface& bvh, const Features
     return stats;
 }
 rt_stats renderImages(const Scene& scene, const BVHInterface& bvh, const Features& features, std::span<const Trackball> cameras,
-                      std::span<Screen> screens, int startDepth, uint32_t flags)
+                      std::span<Screen> screens, int startDepth, uint32_t flags, int gpus)
 {
     if (cameras.size() != screens.size() || cameras.empty()) throw std::invalid_argument("renderImages: one screen per camera, at least one");
     const ivec2 res = screens[0].resolution();
@@ -219,7 +239,13 @@ rt_stats renderImages(const Scene& scene, const BVHInterface& bvh, const Feature
     rt_scene* dev = own ? own->deviceScene() : createDeviceScene(bvh.nodes(), bvh.primitives(), nullptr, scene);
     const rt_features f = toDevice(features);
     rt_stats stats {};
-    const int rc = rt_render_images(dev, cams.data(), (int)cams.size(), &f, res.x, res.y, startDepth, flags, images.data(), &stats);
+    int rc = RT_OK;
+    if (own && gpus != 1) { // every visible GPU (or the first `gpus`) takes its stripes of every frame
+        const std::span<rt_scene* const> team = own->deviceScenes(gpus);
+        rc = rt_render_images_multi(team.data(), (int)team.size(), cams.data(), (int)cams.size(), &f, res.x, res.y, startDepth, flags, images.data(), &stats);
+    } else {
+        rc = rt_render_images(dev, cams.data(), (int)cams.size(), &f, res.x, res.y, startDepth, flags, images.data(), &stats);
+    }
     if (!own) rt_scene_destroy(dev);
     check(rc, "rt_render_images");
     return stats;

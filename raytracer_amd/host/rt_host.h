@@ -152,6 +152,9 @@ public:
     uint32_t numLeaves() const override { return m_numLeaves; }
 
     rt_scene* deviceScene() const { return m_device; }
+    // The device scene on each of the first `gpus` visible GPUs (0 = all of them): the one uploaded at construction and
+    // copies of it made GPU to GPU on first use (rt_scene_clone), kept until the BVH is destroyed.
+    std::span<rt_scene* const> deviceScenes(int gpus = 0) const;
 
 private:
     std::vector<Node> m_nodes;
@@ -159,6 +162,7 @@ private:
     std::vector<Material> m_materials;
     uint32_t m_numLevels = 0, m_numLeaves = 0;
     rt_scene* m_device = nullptr;
+    mutable std::vector<rt_scene*> m_perGpu; // [0] = m_device
 };
 
 // Camera state of the reference's Trackball: Trackball(window, fovy, lookAt, distance, rotationX, rotationY)
@@ -200,8 +204,11 @@ rt_stats renderImage(const Scene& scene, const BVHInterface& bvh, const Features
 
 // The loop that renders one frame per camera (src/main.cpp:515-526): screens[k] from cameras[k], all of one resolution.  The frames
 // are rendered several at a time by one launch sequence each (rt_render_images); every screen holds what renderImage writes for its camera.
+// With a BVH of this library and more than one visible GPU the frames are rendered on all of them (`gpus` = 0) or on the first
+// `gpus`: every frame in interleaved stripes of 8 rows, one GPU per stripe in turn, assembled and bloomed on one GPU per frame
+// (rt_render_images_multi).  gpus = 1 keeps to the GPU the BVH was uploaded to.
 rt_stats renderImages(const Scene& scene, const BVHInterface& bvh, const Features& features, std::span<const Trackball> cameras,
-                      std::span<Screen> screens, int startDepth = 0, uint32_t flags = 0);
+                      std::span<Screen> screens, int startDepth = 0, uint32_t flags = 0, int gpus = 0);
 
 rt_features toDevice(const Features& features);
 
