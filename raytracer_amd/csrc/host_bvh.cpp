@@ -353,14 +353,32 @@ int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, ui
     out = FlatScene {};
     Flattener f { nodes, nNodes, prims, nPrims, primIds, nMaterials, out, msg, sizeof(msg) };
     f.seen.assign(nNodes, 0);
+    {
+        const size_t guess = nPrims / 2 + 16; // (the reference stores every triangle twice; a caller's tree may not)
+        out.triPlane.reserve(guess), out.triEdges.reserve(guess), out.triAttr.reserve(guess), out.leafRoute.reserve(guess);
+        out.leafBox.reserve(6 * guess), out.pairs.reserve(nNodes / 2 + 1), f.arrayPos.reserve(guess);
+    }
     memcpy(out.rootLo, nodes[0].lower, 12);
     memcpy(out.rootHi, nodes[0].upper, 12);
     out.rootRef = f.visit(0, 1, 1u);
     if (f.status != RT_OK) return f.status;
     // Brute-force order (enableAccelStructure off, src/bvh.cpp:351-363) = primitives() array order.
-    std::sort(f.arrayPos.begin(), f.arrayPos.end());
-    out.bruteOrder.resize(f.arrayPos.size());
-    for (size_t i = 0; i < f.arrayPos.size(); i++) out.bruteOrder[i] = f.arrayPos[i].second;
+    // (every position occurs at most once - a leaf range met twice means a node met twice, which visit refuses - so the sort is a scatter)
+    std::vector<uint32_t> atPos(nPrims, 0xffffffffu);
+    bool unique = true;
+    for (const auto& ap : f.arrayPos) {
+        if (atPos[ap.first] != 0xffffffffu) unique = false;
+        atPos[ap.first] = ap.second;
+    }
+    out.bruteOrder.clear();
+    out.bruteOrder.reserve(f.arrayPos.size());
+    if (unique) {
+        for (uint32_t p = 0; p < nPrims; p++)
+            if (atPos[p] != 0xffffffffu) out.bruteOrder.push_back(atPos[p]);
+    } else { // overlapping leaf ranges: positions repeat, keep every occurrence in array order
+        std::sort(f.arrayPos.begin(), f.arrayPos.end());
+        for (const auto& ap : f.arrayPos) out.bruteOrder.push_back(ap.second);
+    }
     return RT_OK;
 }
 
@@ -528,7 +546,7 @@ struct QueryBuilder {
 };
 } // namespace
 
-void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice)
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice, bool hostLayouts)
 {
     out = QueryTree {};
     const uint32_t n = uint32_t(flat.triPlane.size());
@@ -591,6 +609,12 @@ void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice)
         if (out.pairDepth <= 48) break; // a degenerate heuristic tree: fall back to halving
     }
     const auto tLayout = clock::now();
+    out.order = qb.idx;
+    if (!hostLayouts) { // the caller gathers the triangle records by `order` itself (on the device)
+        out.layoutMs += ms_since(tLayout);
+        out.usable = true;
+        return;
+    }
     out.triPlane.resize(n), out.triEdges.resize(n), out.cert.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t t = qb.idx[i];
@@ -604,7 +628,9 @@ void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice)
     }
     // the 4-wide form once more, for four lanes per ray
     out.quadNodes.clear(), out.quadLeaves.clear();
-    if (qb.kLeaf <= 4) {
+    // (only the schedules that run four lanes per ray read it - RT_AMD_QUAD_TRACE, RT_AMD_PATH_QUADS - and it is as large as
+    // everything else of the query tree together)
+    if (qb.kLeaf <= 4 && (getenv("RT_AMD_QUAD_TRACE") || getenv("RT_AMD_PATH_QUADS"))) {
         out.quadNodes.resize(out.nodes.size());
         for (size_t i = 0; i < out.nodes.size(); i++) {
             const Node4& nd = out.nodes[i];

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -1652,6 +1653,27 @@ __global__ void carry_frame_counts_kernel(const uint32_t* qCount, const uint32_t
     if (fallCount) stats[S_FALL_SUM] += *fallCount;
 }
 
+// The triangle records of the query tree: place i of its leaf order holds triangle order[i] of the caller's tree - the plane and
+// edge records copied, and the certificate (the triangle's index, the box of its reference leaf and that leaf's route from
+// the root) put together.  Runs once per scene, after the upload.
+__global__ __launch_bounds__(kBlock) void gather_query_triangles_kernel(const uint32_t* order, const TriPlane* plane, const TriEdges* edges,
+                                                                        const float* leafBox, const uint32_t* leafRoute, const uint32_t n,
+                                                                        TriPlane* qPlane, TriEdges* qEdges, TriCert* qCert)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = order[i];
+    reinterpret_cast<float4*>(qPlane)[i] = reinterpret_cast<const float4*>(plane)[t];
+    const float4* src = reinterpret_cast<const float4*>(edges + t);
+    float4* dst = reinterpret_cast<float4*>(qEdges + i);
+#pragma unroll
+    for (int k = 0; k < 5; k++) dst[k] = src[k];
+    const float* b = leafBox + 6 * (size_t)t;
+    float4* c = reinterpret_cast<float4*>(qCert + i);
+    c[0] = make_float4(b[0], b[1], b[2], __uint_as_float(t));
+    c[1] = make_float4(b[3], b[4], b[5], __uint_as_float(leafRoute[t]));
+}
+
 void gaussian_taps(uint32_t F, float* taps)
 {
     const uint32_t radius = F * 2 + 1;
@@ -1790,6 +1812,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
             return RT_ERR_INVALID;
         }
     }
+    using clock = std::chrono::steady_clock;
+    auto ms_since = [](clock::time_point t0) { return std::chrono::duration<float, std::milli>(clock::now() - t0).count(); };
+    const auto tStart = clock::now();
     FlatScene flat;
     const char* err = "";
     int rc = flatten(static_cast<const RefNode*>(nodes), nNodes, static_cast<const RefPrimitive*>(prims), nPrims, primIds, nMaterials,
@@ -1812,76 +1837,103 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         float* unused = nullptr;
         (void)bloom_static_scratch(s->device, &unused); // set-up on this device: rt_bloom_static finds its array's address resolved
     }
+    const float flattenMs = ms_since(tStart);
+    const auto tQuery = clock::now();
     QueryTree qt;
     // the library's own tree: hierarchy on the device unless RT_AMD_HOST_QUERY_BUILD asks for the host builder
-    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt, getenv("RT_AMD_HOST_QUERY_BUILD") == nullptr);
+    // (its triangle records are gathered on the device, after the upload)
+    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt, getenv("RT_AMD_HOST_QUERY_BUILD") == nullptr, false);
+    const float queryMs = ms_since(tQuery);
+    const auto tUpload = clock::now();
     const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
+    // (the last three: what the query-order copies are gathered from on the device - place -> triangle, and each triangle's
+    // reference leaf box and route; kept in the allocation, read by no kernel afterwards)
     const size_t total = padded(nPairs * sizeof(NodePair)) + padded(nTris * sizeof(TriPlane)) + padded(nTris * sizeof(TriEdges))
         + padded(nTris * sizeof(TriAttr)) + padded(nTris * 4) + padded(flat.leafCounts.size() * 4) + padded((nTris / 32 + 1) * 4) + padded(nMaterials * sizeof(GpuMaterial))
         + padded(nLights * sizeof(GpuLight)) + padded(nSpheres * sizeof(GpuSphere)) + padded(nQNodes * sizeof(Node4)) + padded(nQPairs * sizeof(NodePair))
         + padded(nQTris * sizeof(TriPlane)) + padded(nQTris * sizeof(TriEdges)) + padded(nQTris * sizeof(TriCert))
-        + padded(nQuadNodes * sizeof(QuadNode)) + padded(nQuadLeaves * sizeof(QuadLeaf)) + 256;
-    std::vector<char> host(total, 0);
-    char* hp = host.data();
-    NodePair* hPairs = carve<NodePair>(hp, nPairs);
-    TriPlane* hPlane = carve<TriPlane>(hp, nTris);
-    TriEdges* hEdges = carve<TriEdges>(hp, nTris);
-    TriAttr* hAttr = carve<TriAttr>(hp, nTris);
-    uint32_t* hBrute = carve<uint32_t>(hp, nTris);
-    uint32_t* hLeafCounts = carve<uint32_t>(hp, flat.leafCounts.size());
-    uint32_t* hReflects = carve<uint32_t>(hp, nTris / 32 + 1);
-    GpuMaterial* hMat = carve<GpuMaterial>(hp, nMaterials);
-    GpuLight* hLight = carve<GpuLight>(hp, nLights);
-    GpuSphere* hSph = carve<GpuSphere>(hp, nSpheres);
-    Node4* hQNodes = carve<Node4>(hp, nQNodes);
-    NodePair* hQPairs = carve<NodePair>(hp, nQPairs);
-    TriPlane* hQPlane = carve<TriPlane>(hp, nQTris);
-    TriEdges* hQEdges = carve<TriEdges>(hp, nQTris);
-    TriCert* hQCert = carve<TriCert>(hp, nQTris);
-    QuadNode* hQuadNodes = carve<QuadNode>(hp, nQuadNodes);
-    QuadLeaf* hQuadLeaves = carve<QuadLeaf>(hp, nQuadLeaves);
-    if (qt.usable) {
-        if (nQuadNodes) memcpy(hQuadNodes, qt.quadNodes.data(), nQuadNodes * sizeof(QuadNode));
-        if (nQuadLeaves) memcpy(hQuadLeaves, qt.quadLeaves.data(), nQuadLeaves * sizeof(QuadLeaf));
-        memcpy(hQNodes, qt.nodes.data(), nQNodes * sizeof(Node4));
-        memcpy(hQPairs, qt.pairs.data(), nQPairs * sizeof(NodePair));
-        memcpy(hQPlane, qt.triPlane.data(), nQTris * sizeof(TriPlane));
-        memcpy(hQEdges, qt.triEdges.data(), nQTris * sizeof(TriEdges));
-        memcpy(hQCert, qt.cert.data(), nQTris * sizeof(TriCert));
+        + padded(nQuadNodes * sizeof(QuadNode)) + padded(nQuadLeaves * sizeof(QuadLeaf)) + padded(nQTris * 4) + padded(nQTris * 24) + padded(nQTris * 4) + 256;
+    // the small tables, as the kernels read them
+    std::vector<uint32_t> hReflects(nTris / 32 + 1, 0u);
+    for (size_t i = 0; i < nTris; i++) { // the material test of renderRay (src/recursive.cpp:62-80), once per triangle
+        const float* m = materials8 + 8 * (size_t)flat.triAttr[i].meshID;
+        if (m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f) hReflects[i >> 5] |= 1u << (i & 31);
     }
-    if (nPairs) memcpy(hPairs, flat.pairs.data(), nPairs * sizeof(NodePair));
-    if (nTris) {
-        memcpy(hPlane, flat.triPlane.data(), nTris * sizeof(TriPlane));
-        memcpy(hEdges, flat.triEdges.data(), nTris * sizeof(TriEdges));
-        memcpy(hAttr, flat.triAttr.data(), nTris * sizeof(TriAttr));
-        memcpy(hBrute, flat.bruteOrder.data(), nTris * 4);
-        if (!flat.leafCounts.empty()) memcpy(hLeafCounts, flat.leafCounts.data(), flat.leafCounts.size() * 4);
-        for (size_t i = 0; i < nTris; i++) { // the material test of renderRay (src/recursive.cpp:62-80), once per triangle
-            const float* m = materials8 + 8 * (size_t)flat.triAttr[i].meshID;
-            if (m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f) hReflects[i >> 5] |= 1u << (i & 31);
-        }
-    }
+    std::vector<GpuMaterial> hMat(nMaterials);
     for (uint32_t i = 0; i < nMaterials; i++) {
         const float* m = materials8 + 8 * (size_t)i;
         hMat[i] = GpuMaterial { { m[0], m[1], m[2] }, m[6], { m[3], m[4], m[5] }, m[7] };
     }
+    std::vector<GpuLight> hLight(nLights);
     for (uint32_t i = 0; i < nLights; i++) {
         const float* l = lights22 + 22 * (size_t)i;
         hLight[i].type = l[0];
         memcpy(hLight[i].f, l + 1, 21 * 4);
         hLight[i].pad[0] = hLight[i].pad[1] = 0.0f;
     }
+    std::vector<GpuSphere> hSph(nSpheres);
     for (uint32_t i = 0; i < nSpheres; i++) {
         const float* p = spheres12 + 12 * (size_t)i;
         hSph[i] = GpuSphere { { p[0], p[1], p[2] }, p[3], { p[4], p[5], p[6] }, p[10], { p[7], p[8], p[9] }, p[11] };
     }
+    // One allocation, every array copied into its place straight from where it was built (no second copy on the host); the
+    // triangle records in query-tree order and their certificates are gathered from the uploaded ones by a kernel.
     hipError_t e = hipMalloc(&s->d_blob, total);
-    if (e == hipSuccess) e = hipMemcpy(s->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    char* up = static_cast<char*>(s->d_blob);
+    auto put = [&](auto*& d, const void* src, size_t count) { // carves `count` records for d and fills them from src (null: left as they are)
+        using T = std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(d)>>>;
+        d = carve<T>(up, count);
+        if (e == hipSuccess && src && count) e = hipMemcpy(const_cast<T*>(d), src, count * sizeof(T), hipMemcpyHostToDevice);
+    };
+    const NodePair *uPairs = nullptr, *uQPairs = nullptr;
+    const TriPlane *uPlane = nullptr, *uQPlane = nullptr;
+    const TriEdges *uEdges = nullptr, *uQEdges = nullptr;
+    const TriAttr* uAttr = nullptr;
+    const uint32_t *uBrute = nullptr, *uLeafCounts = nullptr, *uReflects = nullptr, *uOrder = nullptr, *uRoute = nullptr;
+    const GpuMaterial* uMat = nullptr;
+    const GpuLight* uLight = nullptr;
+    const GpuSphere* uSph = nullptr;
+    const Node4* uQNodes = nullptr;
+    const TriCert* uQCert = nullptr;
+    const QuadNode* uQuadNodes = nullptr;
+    const QuadLeaf* uQuadLeaves = nullptr;
+    struct Box6 {
+        float v[6];
+    };
+    const Box6* uLeafBox = nullptr;
+    if (e == hipSuccess) {
+        put(uPairs, flat.pairs.data(), nPairs);
+        put(uPlane, flat.triPlane.data(), nTris);
+        put(uEdges, flat.triEdges.data(), nTris);
+        put(uAttr, flat.triAttr.data(), nTris);
+        put(uBrute, flat.bruteOrder.data(), nTris);
+        put(uLeafCounts, flat.leafCounts.data(), flat.leafCounts.size());
+        put(uReflects, hReflects.data(), nTris / 32 + 1);
+        put(uMat, hMat.data(), nMaterials);
+        put(uLight, hLight.data(), nLights);
+        put(uSph, hSph.data(), nSpheres);
+        put(uQNodes, qt.nodes.data(), nQNodes);
+        put(uQPairs, qt.pairs.data(), nQPairs);
+        put(uQPlane, qt.triPlane.empty() ? nullptr : qt.triPlane.data(), nQTris);
+        put(uQEdges, qt.triEdges.empty() ? nullptr : qt.triEdges.data(), nQTris);
+        put(uQCert, qt.cert.empty() ? nullptr : qt.cert.data(), nQTris);
+        put(uQuadNodes, qt.quadNodes.data(), nQuadNodes);
+        put(uQuadLeaves, qt.quadLeaves.data(), nQuadLeaves);
+        put(uOrder, qt.order.data(), nQTris);
+        put(uLeafBox, flat.leafBox.data(), nQTris);
+        put(uRoute, flat.leafRoute.data(), nQTris);
+        if (e == hipSuccess && nQTris && qt.triPlane.empty()) { // (the host did not gather them)
+            hipLaunchKernelGGL(gather_query_triangles_kernel, dim3((unsigned)((nQTris + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, uOrder, uPlane,
+                               uEdges, reinterpret_cast<const float*>(uLeafBox), uRoute, (uint32_t)nQTris, const_cast<TriPlane*>(uQPlane),
+                               const_cast<TriEdges*>(uQEdges), const_cast<TriCert*>(uQCert));
+            e = hipGetLastError();
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // frames run on streams the null stream's memset is not ordered with
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // frames run on streams the null stream's work is not ordered with
     s->texturePixels.assign(nMaterials, nullptr);
     if (e != hipSuccess) {
         rt::set_error("rt_scene_create: device allocation/upload of %zu bytes failed: %s", total, hipGetErrorString(e));
@@ -1927,6 +1979,9 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         s->queryDepth = qt.pairDepth;
         s->queryDepth4 = qt.maxDepth;
     }
+    if (getenv("RT_AMD_VERBOSE"))
+        fprintf(stderr, "rt_scene_create: %.2f ms: flattening the caller's tree %.2f, query tree %.2f, assembling and uploading %zu bytes %.2f\n",
+                ms_since(tStart), flattenMs, queryMs, total, ms_since(tUpload));
     if (getenv("RT_AMD_VERBOSE"))
         fprintf(stderr, "rt_scene_create: %zu triangles, reference tree %zu pairs depth %u, query tree %zu pairs depth %u = %zu 4-wide nodes depth %u%s; "
                         "hierarchy built on the %s in %.2f ms (launches %.2f ms), layouts written in %.2f ms\n",

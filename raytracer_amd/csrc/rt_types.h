@@ -179,6 +179,8 @@ struct QueryTree {
     std::vector<TriPlane> triPlane; // copies in query-tree leaf order
     std::vector<TriEdges> triEdges;
     std::vector<TriCert> cert;
+    std::vector<uint32_t> order;    // query-tree place -> compact triangle (what the three arrays above are gathered by; they stay empty
+                                    // when the caller gathers on the device: build_query_tree's hostLayouts = false)
     uint32_t rootRef = 0;
     uint32_t maxDepth = 0;
     bool usable = false;
@@ -188,7 +190,8 @@ struct QueryTree {
     float layoutMs = 0.0f;       // wall time of writing the traversal layouts from the hierarchy (host)
 };
 // onDevice: try the device builder first (the host builder takes over if it cannot be used)
-void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice = false);
+// hostLayouts: also gather the triangle records and certificates into query-tree order on the host (the self-tests read them)
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice = false, bool hostLayouts = true);
 
 // One node of a hierarchy built on the device: a child is a node index or a leaf reference (kLeafBit | count << 25 | first place in the
 // triangle order).
