@@ -133,6 +133,16 @@ int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out);
  * undefined on: more than four triangles with one centroid coordinate on their split axis (the bin index is
  * 0/0 converted to size_t).  rt_scene_create accepts leaves of any size and trees of up to 32 levels. */
 int rt_bvh_build_sah_binning(const void* prims, uint32_t nPrims, rt_bvh** out);
+/* The same two constructors with the spans settled on the current GPU (sahBinning: 0 = rt_bvh_build's tree, non-zero =
+ * rt_bvh_build_sah_binning's): per level one pass computes every span's box, sorts every span by its centroid coordinate on the
+ * span's longest axis (src/bvh.cpp:181-214) and decides its split (median, or src/extra.cpp:623-699); the node numbering and the
+ * doubled primitive array (src/bvh.cpp:387-392, 429-512) are then written on the host.  nodes() / primitives() come out bit for
+ * bit as from the host builds.  Where the reference's result depends on the ORDER its code meets the primitives in - two equal
+ * sort keys in a span (std::sort's order), or a box coordinate that is zero with both signs present - the span is handed to the
+ * host builder together with everything below it.  info (may be null): [0] spans settled on the device, [1] spans handed to
+ * the host, [2] levels launched, [3] primitives inside the spans handed to the host.  RT_ERR_HIP when no GPU can be used
+ * (rt_bvh_build needs none); the errors of the host builds otherwise. */
+int rt_bvh_build_device(const void* prims, uint32_t nPrims, int sahBinning, rt_bvh** out, uint32_t info[4]);
 void rt_bvh_destroy(rt_bvh* bvh);
 /* BVHInterface::nodes() / primitives() / numLevels() / numLeaves() (src/bvh_interface.h:64-71).
  * Nodes are 32 bytes (src/bvh_interface.h:28-54), index 1 is the reference's unused dummy; primitives

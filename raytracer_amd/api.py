@@ -97,6 +97,7 @@ def lib():
     L.rt_last_error.restype = C.c_char_p
     L.rt_bvh_build.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.rt_bvh_build_sah_binning.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.rt_bvh_build_device.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint32)]
     L.rt_bvh_destroy.argtypes = [vp]
     for n in ("rt_bvh_num_nodes", "rt_bvh_num_primitives", "rt_bvh_num_levels", "rt_bvh_num_leaves"):
         getattr(L, n).restype = C.c_uint32
@@ -156,13 +157,20 @@ def camera_from_trackball(width, height, fov_deg=50.0, dist=3.0, look_at=(0.0, 0
 
 
 class Bvh:
-    """Host BVH in the reference's nodes()/primitives() layout (rt_bvh_build; rt_bvh_build_sah_binning with sah_binning)."""
+    """Host BVH in the reference's nodes()/primitives() layout (rt_bvh_build; rt_bvh_build_sah_binning with sah_binning;
+    rt_bvh_build_device with device=True: the same arrays, spans settled on the GPU, `device_info` = its four counters)."""
 
-    def __init__(self, prims25, sah_binning=False):
+    def __init__(self, prims25, sah_binning=False, device=False):
         self.input = np.ascontiguousarray(prims25, np.uint32).reshape(-1, 25)
         h = C.c_void_p()
-        build = lib().rt_bvh_build_sah_binning if sah_binning else lib().rt_bvh_build
-        check(build(self.input.ctypes.data, len(self.input), C.byref(h)))
+        self.device_info = None
+        if device:
+            info = (C.c_uint32 * 4)()
+            check(lib().rt_bvh_build_device(self.input.ctypes.data, len(self.input), 1 if sah_binning else 0, C.byref(h), info))
+            self.device_info = dict(device_spans=info[0], host_spans=info[1], levels=info[2], host_primitives=info[3])
+        else:
+            build = lib().rt_bvh_build_sah_binning if sah_binning else lib().rt_bvh_build
+            check(build(self.input.ctypes.data, len(self.input), C.byref(h)))
         self.h = h
 
     def __del__(self):

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librt_amd.so")
-SOURCES = ["rt_device.hip", "query_build.hip", "host_bvh.cpp", "rt_multi.cpp"]
+SOURCES = ["rt_device.hip", "query_build.hip", "ref_build.hip", "host_bvh.cpp", "rt_multi.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "rt_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-Wall", "-Wno-unused-function"]

@@ -42,6 +42,7 @@ struct Builder {
     bool sahBinning = false; // features.extra.enableBvhSahBinning (src/common.h:63)
     bool undefined = false;  // a span's centroids coincide on its split axis: the reference's bin index is 0/0 there
     std::vector<float> leftArea; // surface area of the box around the first k primitives of the sorted span
+    std::vector<uint8_t> filled; // device build: primitives whose lo / hi / centroid entries are in place
 
     static float surfaceArea(vec3 lower, vec3 upper) // calculateAABBSurfaceArea (src/extra.cpp:609-613)
     {
@@ -671,6 +672,47 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_error; }
 
+// Per-primitive boxes and centroids, the root and the reference's dummy second node: what Builder::build starts from.
+static void builder_begin(Builder& bl, rt_bvh* b, const void* prims, uint32_t nPrims, bool sahBinning, bool perPrimitive)
+{
+    bl.in = static_cast<const RefPrimitive*>(prims);
+    bl.out = b;
+    bl.sahBinning = sahBinning;
+    if (perPrimitive) {
+        bl.lo.resize(nPrims);
+        bl.hi.resize(nPrims);
+        bl.centroid.resize(nPrims);
+        for (uint32_t i = 0; i < nPrims; i++) {
+            const RefPrimitive& p = bl.in[i];
+            const vec3 a = load3(p.v0.position), c = load3(p.v1.position), d = load3(p.v2.position);
+            bl.lo[i] = gmin(gmin(a, c), d); // computePrimitiveAABB operand order (src/bvh.cpp:111-118)
+            bl.hi[i] = gmax(gmax(a, c), d);
+            bl.centroid[i] = (a + c + d) / 3.0f; // computePrimitiveCentroid (src/bvh.cpp:144-152)
+        }
+    }
+    b->prims.reserve(size_t(nPrims) * 2);
+    b->primIds.reserve(size_t(nPrims) * 2);
+    b->nodes.reserve(size_t(nPrims) + 2);
+    b->nodes.emplace_back(); // root
+    b->nodes.emplace_back(); // the reference's dummy second node (src/bvh.cpp:82): default box, zero data
+    RefNode& dummy = b->nodes[1];
+    dummy.lower[0] = dummy.lower[1] = dummy.lower[2] = 0.0f;
+    dummy.upper[0] = dummy.upper[1] = dummy.upper[2] = 1.0f;
+    dummy.data[0] = dummy.data[1] = 0;
+}
+static int builder_end(Builder& bl, rt_bvh* b, rt_bvh** out)
+{
+    if (bl.undefined) {
+        delete b;
+        set_error("rt_bvh_build_sah_binning: more than four triangles share their centroid coordinate on the split axis; the "
+                  "reference's bin index (src/extra.cpp:590-598) is 0/0 converted to size_t for them, which is undefined");
+        return RT_ERR_INVALID;
+    }
+    countLevelsAndLeaves(*b);
+    *out = b;
+    return RT_OK;
+}
+
 static int bvh_build(const void* prims, uint32_t nPrims, bool sahBinning, rt_bvh** out);
 int rt_bvh_build(const void* prims, uint32_t nPrims, rt_bvh** out) { return bvh_build(prims, nPrims, false, out); }
 int rt_bvh_build_sah_binning(const void* prims, uint32_t nPrims, rt_bvh** out) { return bvh_build(prims, nPrims, true, out); }
@@ -687,40 +729,112 @@ static int bvh_build(const void* prims, uint32_t nPrims, bool sahBinning, rt_bvh
         return RT_ERR_NOMEM;
     }
     Builder bl;
-    bl.in = static_cast<const RefPrimitive*>(prims);
-    bl.out = b;
-    bl.lo.resize(nPrims);
-    bl.hi.resize(nPrims);
-    bl.centroid.resize(nPrims);
+    builder_begin(bl, b, prims, nPrims, sahBinning, true);
     bl.order.resize(nPrims);
-    for (uint32_t i = 0; i < nPrims; i++) {
-        const RefPrimitive& p = bl.in[i];
-        const vec3 a = load3(p.v0.position), c = load3(p.v1.position), d = load3(p.v2.position);
-        bl.lo[i] = gmin(gmin(a, c), d); // computePrimitiveAABB operand order (src/bvh.cpp:111-118)
-        bl.hi[i] = gmax(gmax(a, c), d);
-        bl.centroid[i] = (a + c + d) / 3.0f; // computePrimitiveCentroid (src/bvh.cpp:144-152)
-        bl.order[i] = i;
-    }
-    b->prims.reserve(size_t(nPrims) * 2);
-    b->primIds.reserve(size_t(nPrims) * 2);
-    b->nodes.reserve(size_t(nPrims) + 2);
-    b->nodes.emplace_back(); // root
-    b->nodes.emplace_back(); // the reference's dummy second node (src/bvh.cpp:82): default box, zero data
-    RefNode& dummy = b->nodes[1];
-    dummy.lower[0] = dummy.lower[1] = dummy.lower[2] = 0.0f;
-    dummy.upper[0] = dummy.upper[1] = dummy.upper[2] = 1.0f;
-    dummy.data[0] = dummy.data[1] = 0;
-    bl.sahBinning = sahBinning;
+    for (uint32_t i = 0; i < nPrims; i++) bl.order[i] = i;
     bl.build(bl.order.data(), nPrims, 0);
-    if (bl.undefined) {
-        delete b;
-        set_error("rt_bvh_build_sah_binning: more than four triangles share their centroid coordinate on the split axis; the "
-                  "reference's bin index (src/extra.cpp:590-598) is 0/0 converted to size_t for them, which is undefined");
+    return builder_end(bl, b, out);
+}
+
+namespace {
+// BVH::buildRecursive's numbering (src/bvh.cpp:429-512) over spans that are already settled: a node's two children get the
+// next two node indices when the node is reached, then the left subtree is numbered, then the right; a leaf's primitives
+// are appended twice and the leaf points at the second copy (see Builder::build, which this hands over to for a span the
+// device left to the host).
+struct SpanAssembler {
+    Builder& bl;
+    const std::vector<RefBuildNode>& tree;
+    uint32_t* order;
+    uint32_t nPrims;
+    uint32_t hostPrims = 0;
+    bool prepared = false;
+
+    void place(uint32_t t, uint32_t nodeIndex)
+    {
+        const RefBuildNode& T = tree[t];
+        rt_bvh* const out = bl.out;
+        if (T.split == kRefBuildHost) {
+            if (!prepared) { // the host builder's per-primitive tables, for the primitives of the spans it gets
+                prepared = true;
+                bl.lo.resize(nPrims), bl.hi.resize(nPrims), bl.centroid.resize(nPrims);
+                bl.filled.assign(nPrims, 0);
+            }
+            for (uint32_t k = 0; k < T.count; k++) {
+                const uint32_t i = order[T.begin + k];
+                if (bl.filled[i]) continue;
+                bl.filled[i] = 1;
+                const RefPrimitive& p = bl.in[i];
+                const vec3 a = load3(p.v0.position), c = load3(p.v1.position), d = load3(p.v2.position);
+                bl.lo[i] = gmin(gmin(a, c), d);
+                bl.hi[i] = gmax(gmax(a, c), d);
+                bl.centroid[i] = (a + c + d) / 3.0f;
+            }
+            hostPrims += T.count;
+            bl.build(order + T.begin, T.count, nodeIndex);
+            return;
+        }
+        RefNode node;
+        for (int k = 0; k < 3; k++) node.lower[k] = T.lo[k], node.upper[k] = T.hi[k];
+        if (T.split == 0) {
+            bl.emitLeafCopy(order + T.begin, T.count);
+            node.data[0] = uint32_t(out->prims.size()) | kLeafBit;
+            node.data[1] = T.count;
+            out->nodes[nodeIndex] = node;
+            bl.emitLeafCopy(order + T.begin, T.count);
+            return;
+        }
+        const uint32_t left = uint32_t(out->nodes.size());
+        out->nodes.emplace_back();
+        out->nodes.emplace_back();
+        node.data[0] = left;
+        node.data[1] = left + 1;
+        out->nodes[nodeIndex] = node;
+        place(T.left, left);
+        place(T.left + 1, left + 1);
+    }
+};
+} // namespace
+
+int rt_bvh_build_device(const void* prims, uint32_t nPrims, int sahBinning, rt_bvh** out, uint32_t info[4])
+{
+    if (info) info[0] = info[1] = info[2] = info[3] = 0u;
+    if (nPrims <= 4u) return bvh_build(prims, nPrims, sahBinning != 0, out); // the root is a leaf: nothing to sort
+    if (!out || !prims) {
+        set_error("rt_bvh_build_device: null argument");
         return RT_ERR_INVALID;
     }
-    countLevelsAndLeaves(*b);
-    *out = b;
-    return RT_OK;
+    *out = nullptr;
+    std::vector<RefBuildNode> tree;
+    std::vector<uint32_t> order;
+    uint32_t stats[4] = { 0, 0, 0, 0 };
+    const bool verbose = getenv("RT_AMD_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    float kernelMs = 0.0f;
+    if (!device_build_reference_spans(static_cast<const RefPrimitive*>(prims), nPrims, sahBinning != 0, tree, order, stats, &kernelMs)) {
+        set_error("rt_bvh_build_device: the device build did not complete (no usable GPU, out of device memory, or a tree deeper than "
+                  "96 levels); rt_bvh_build builds on the host");
+        return RT_ERR_HIP;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    rt_bvh* b = new (std::nothrow) rt_bvh();
+    if (!b) {
+        set_error("rt_bvh_build_device: out of memory");
+        return RT_ERR_NOMEM;
+    }
+    Builder bl;
+    builder_begin(bl, b, prims, nPrims, sahBinning != 0, false);
+    SpanAssembler as { bl, tree, order.data(), nPrims };
+    as.place(0u, 0u);
+    if (info) info[0] = stats[0], info[1] = stats[1], info[2] = stats[2], info[3] = as.hostPrims;
+    const int rc = builder_end(bl, b, out);
+    if (verbose) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "rt_bvh_build_device: %u primitives, %u spans in %u levels on the device (%.2f ms, launches %.2f), %u spans with %u primitives "
+                        "left to the host; numbering and copying %.2f ms\n",
+                nPrims, stats[0], stats[2], std::chrono::duration<double, std::milli>(t1 - t0).count(), kernelMs, stats[1], as.hostPrims,
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
+    return rc;
 }
 void rt_bvh_destroy(rt_bvh* bvh) { delete bvh; }
 uint32_t rt_bvh_num_nodes(const rt_bvh* b) { return b ? uint32_t(b->nodes.size()) : 0; }

@@ -202,6 +202,18 @@ struct DeviceBuildNode {
 bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
                                   std::vector<uint32_t>& order, uint32_t& depth, float* kernelMs);
 
+// One span of the reference's build as settled on the device (device_build_reference_spans): its box, its place in the primitive
+// order, the level it was decided at, and what became of it - split == 0: a leaf; split == kRefBuildHost: the host builds the
+// subtree from the order the span was given (see ref_build.hip); otherwise the left child (record `left`) holds the first `split`
+// primitives and the right child (record `left + 1`) the rest.
+constexpr uint32_t kRefBuildHost = 0xffffffffu;
+struct RefBuildNode {
+    float lo[3], hi[3];
+    uint32_t begin, count, split, left, level, pad;
+};
+bool device_build_reference_spans(const RefPrimitive* prims, uint32_t n, bool sah, std::vector<RefBuildNode>& tree, std::vector<uint32_t>& order,
+                                  uint32_t info[4], float* kernelMs);
+
 // Returns RT_OK or an error status with `err` describing it.
 int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,
             uint32_t nMaterials, FlatScene& out, const char** err);

@@ -1,0 +1,103 @@
+"""rt_bvh_build_device: the reference-layout tree with its spans settled on the GPU, against rt_bvh_build /
+rt_bvh_build_sah_binning (which test_host_cpu.py pins to the oracle's restatement of reference src/bvh.cpp:429-512 and
+src/extra.cpp:582-699).  nodes() / primitives() / primitive ids / level and leaf counts must be the same bits."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["triangle", "cube", "cornell", "monkey", "teapot", "spheres", "knot", "dragon"]
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from raytracer_amd import api
+    return api
+
+
+def _scene_triangles(name):
+    from raytracer_amd import scenes
+    if name in ("knot", "dragon"):
+        sc = scenes.dragon_standin(n_u=120, n_v=24) if name == "knot" else scenes.dragon_standin()
+        return sc["prims"]
+    return O.load_scene_arrays(name)[0]
+
+
+def _same(rt, prims, sah):
+    host = rt.Bvh(prims, sah_binning=sah)
+    dev = rt.Bvh(prims, sah_binning=sah, device=True)
+    assert dev.num_levels == host.num_levels and dev.num_leaves == host.num_leaves
+    assert np.array_equal(dev.nodes(), host.nodes())
+    assert np.array_equal(dev.primitives(), host.primitives())
+    assert np.array_equal(dev.primitive_ids(), host.primitive_ids())
+    return dev.device_info
+
+
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+@pytest.mark.parametrize("name", SCENES)
+def test_device_built_tree_is_the_host_built_tree(rt, name, sah):
+    prims = _scene_triangles(name)
+    info = _same(rt, prims, sah)
+    if len(prims) > 4:
+        assert info["device_spans"] >= 1 and info["levels"] >= 1
+    if name in ("knot", "dragon"):  # generic coordinates: equal keys are rare, the device settles (nearly) every span
+        assert info["host_primitives"] * 100 <= len(prims), info
+
+
+def _grid(n, jitter, seed):
+    """n x n quads in the plane z = 0 (two triangles each): centroids repeat along both axes unless jittered."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.arange(n + 1, dtype=np.float32), np.arange(n + 1, dtype=np.float32), indexing="ij")
+    z = np.zeros_like(xs)
+    if jitter:
+        xs = xs + rng.uniform(-0.3, 0.3, xs.shape).astype(np.float32)
+        ys = ys + rng.uniform(-0.3, 0.3, ys.shape).astype(np.float32)
+        z = rng.uniform(-0.3, 0.3, xs.shape).astype(np.float32)
+    P = np.stack([xs, ys, z], axis=-1)
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = P[i, j], P[i + 1, j], P[i + 1, j + 1], P[i, j + 1]
+            tris.append((a, b, c))
+            tris.append((a, c, d))
+    prims = np.zeros((len(tris), 25), np.float32)
+    for k, (a, b, c) in enumerate(tris):
+        for v, p in enumerate((a, b, c)):
+            prims[k, 1 + 8 * v:4 + 8 * v] = p
+            prims[k, 4 + 8 * v:7 + 8 * v] = (0.0, 0.0, 1.0)
+    return prims.view(np.uint32)
+
+
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+def test_spans_with_equal_sort_keys_go_to_the_host_builder(rt, sah):
+    """A regular grid: whole rows of triangles share a centroid coordinate, so the order std::sort leaves them in is part
+    of the reference's result.  The device must notice and hand those spans over; the tree is still the host's."""
+    prims = _grid(24, False, 1)
+    info = _same(rt, prims, sah)
+    assert info["host_spans"] >= 1 and info["host_primitives"] >= 1
+
+
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+def test_a_jittered_grid_is_built_on_the_device_alone(rt, sah):
+    info = _same(rt, _grid(40, True, 2), sah)
+    assert info["host_spans"] == 0 and info["device_spans"] > 100
+
+
+def test_signed_zeros_in_a_box_go_to_the_host_builder(rt):
+    """glm::min keeps the first of +0 and -0 it meets: a span whose box coordinate is zero with both signs present depends on
+    the order of the fold."""
+    prims = _grid(12, True, 3).view(np.float32).copy()
+    prims[:, 3::8][:, :3] = np.abs(prims[:, 3::8][:, :3])  # z >= 0 ...
+    prims[0, 3] = 0.0
+    prims[5, 3] = -0.0  # ... with the minimum 0 present under both signs
+    info = _same(rt, prims.view(np.uint32), False)
+    assert info["host_spans"] >= 1
+
+
+def test_five_primitives_and_fewer(rt):
+    base = _grid(3, True, 4)
+    for n in (0, 1, 4, 5, 6, 9):
+        _same(rt, base[:n], False)
+        _same(rt, base[:n], True)
