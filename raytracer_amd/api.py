@@ -238,9 +238,10 @@ class Scene:
             self.set_texture(m, img)
 
     @classmethod
-    def from_triangles(cls, prims25, materials, lights, spheres=None, textures=None, sah_binning=False):
-        """Scene triangles in gather order -> rt_bvh_build (or rt_bvh_build_sah_binning) -> rt_scene_create."""
-        bvh = Bvh(prims25, sah_binning)
+    def from_triangles(cls, prims25, materials, lights, spheres=None, textures=None, sah_binning=False, device_build=True):
+        """Scene triangles in gather order -> rt_bvh_build_device (device_build=False: rt_bvh_build or rt_bvh_build_sah_binning on
+        the host; the same arrays) -> rt_scene_create."""
+        bvh = Bvh(prims25, sah_binning, device=device_build)
         s = cls(bvh.nodes(), bvh.primitives(), bvh.primitive_ids(), materials, lights, spheres, textures)
         s.bvh = bvh
         return s

@@ -1,4 +1,6 @@
 #include "rt_host.h"
+
+#include <cstdlib>
 #include "../csrc/rt_math.h"
 #include <algorithm>
 #include <cmath>
@@ -94,7 +96,12 @@ BVH::BVH(const Scene& scene, const Features& features)
         for (const uvec3& t : mesh.triangles) gathered.push_back(Primitive { m, mesh.vertices[t.x], mesh.vertices[t.y], mesh.vertices[t.z] });
     }
     rt_bvh* h = nullptr;
-    if (features.extra.enableBvhSahBinning) // src/bvh.cpp:472-499
+    // The spans are settled on the GPU the scene is about to live on (the same nodes() / primitives() bit for bit);
+    // RT_AMD_HOST_BUILD=1 keeps the whole build on the host.
+    const char* hostBuild = getenv("RT_AMD_HOST_BUILD");
+    if (!hostBuild || !*hostBuild || *hostBuild == '0')
+        check(rt_bvh_build_device(gathered.data(), (uint32_t)gathered.size(), features.extra.enableBvhSahBinning ? 1 : 0, &h, nullptr), "rt_bvh_build_device");
+    else if (features.extra.enableBvhSahBinning) // src/bvh.cpp:472-499
         check(rt_bvh_build_sah_binning(gathered.data(), (uint32_t)gathered.size(), &h), "rt_bvh_build_sah_binning");
     else
         check(rt_bvh_build(gathered.data(), (uint32_t)gathered.size(), &h), "rt_bvh_build");
