@@ -217,6 +217,7 @@ def main():
         if float(probe_ms.item()) < 3.0:
             K = 2
         del probe
+        scene.trim()  # the probe's buffers (a scene's first frame is given room for the worst case); what it held sizes the sequences' buffers
     if by_frames:  # every rank cuts its own frames into sequences of the same size: the smallest any rank arrived at
         kk = torch.tensor([float(K)], dtype=torch.float64)
         if args.backend == "nccl":

@@ -185,7 +185,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
                     const float* spheres12, uint32_t nSpheres, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 /* Releases what the scene has allocated for rendering - the working buffers of every stream frames were queued on (about
- * 3 KB per pixel of the largest launch sequence each), the frame buffers of rt_render_image(s) - after waiting for the
+ * 3 KB per pixel for a scene's first frame, which is given room for the worst case the pipeline accepts - eight tasks per pixel;
+ * later allocations hold half as much again as the fullest task queues and the largest round of the scene's completed frames,
+ * about 1 KB per pixel for the headline frame, and a frame that needs more reports RT_ERR_AGAIN and makes them grow;
+ * RT_AMD_FULL_QUEUES=1 keeps the worst case), the frame buffers of rt_render_image(s) - after waiting for the
  * device; the scene itself stays uploaded and the next render allocates again.  No counterpart in the reference (a
  * Scene there owns no render state); for callers that keep many scenes alive on one GPU.  Counters of frames not yet
  * fetched with rt_sync are lost. */
@@ -255,7 +258,6 @@ int rt_bloom_static(float* d_rgb, int width, int height, uint32_t filterSize, fl
  * rays each round of the frame held: the next rt_render of the same size, depth, flags, features and region leaves out
  * the launches that only serve larger rounds (a hint - the frame is the same whatever the plan says). */
 int rt_sync(rt_scene* scene, void* stream, rt_stats* stats);
-
 /* renderImage (src/render.cpp:19-51) for host callers: render + optional bloom + copy back.
  * rgb: HOST W*H*3 floats = Screen::pixels() (src/screen.h:25-26).  primId / primT: optional HOST
  * W*H arrays.  Multi-sample, depth-of-field and motion-blur drivers are not part of this path. */

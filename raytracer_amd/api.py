@@ -3,6 +3,7 @@
 The library is the product; this module only marshals arrays.  There is no CPU fallback: if the
 shared library is missing, loading raises."""
 import ctypes as C
+import weakref
 import os
 import sys
 
@@ -217,6 +218,16 @@ def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t) if t is not C.c_void_p else C.c_void_p(a.ctypes.data)
 
 
+_live_scenes = weakref.WeakSet()  # every Scene alive in this process (trim_all)
+
+
+def trim_all():
+    """rt_scene_trim on every live Scene of this process: for hosts that keep many scenes on one GPU."""
+    for s in list(_live_scenes):
+        if getattr(s, "h", None):
+            s.trim()
+
+
 class Scene:
     """Device-resident scene (rt_scene_create) built from reference-layout arrays."""
 
@@ -234,6 +245,7 @@ class Scene:
                                     _p(self.materials, f32p), len(self.materials), _p(self.lights, f32p), len(self.lights),
                                     _p(self.spheres, f32p), len(self.spheres), C.byref(h)))
         self.h = h
+        _live_scenes.add(self)
         for m, img in (textures or {}).items():
             self.set_texture(m, img)
 
@@ -291,6 +303,7 @@ class Scene:
         check(lib().rt_scene_clone(self.h, device, C.byref(h)))
         other = object.__new__(Scene)
         other.h = h
+        _live_scenes.add(other)
         for name in ("nodes", "prims", "prim_ids", "materials", "lights", "spheres", "bvh"):
             if hasattr(self, name):
                 setattr(other, name, getattr(self, name))

@@ -18,6 +18,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace rt;
@@ -42,7 +43,7 @@ struct Workspace {
     size_t stateWords = 0;          // ... its size in floats
     float* d_frames = nullptr;      // rounds: pending glossy loops, by rayDepth then state (WaveParams::frameBase)
     float* d_passes = nullptr;      // rounds with transparency: pending pass-through rays, by rayDepth then state
-    size_t frameStates = 0, passStates = 0; // states the two hold
+    size_t frameStates = 0, passStates = 0; // states x levels the two hold
     uint32_t* d_active[2] = { nullptr, nullptr };
     uint32_t* d_activeRay[2] = { nullptr, nullptr }; // first ray of each active state
     size_t pathRayCap = 0;
@@ -69,6 +70,8 @@ struct Workspace {
     // larger rounds.  The plan is a hint: a round that turns out larger is still traced completely, by the group kernel alone.
     uint64_t lastKey = 0; // what shaped the rounds of the frame last queued here
     uint32_t lastRounds = 0;
+    uint32_t lastWork = 0; // pixels (of all its frames) of the last wavefront sequence
+    uint64_t lastCfg = 0;  // ... and the description its queue sizes are remembered under (rt_scene::seenQueues)
 };
 
 struct RetiredFrame {
@@ -115,7 +118,15 @@ struct rt_scene {
     uint64_t planKey = 0;
     // task queue sizes a frame of this scene has asked for (a frame that overflowed its queues is reported by rt_sync with
     // RT_ERR_AGAIN; the next rt_render allocates these)
-    uint64_t wantShadeTasks = 0, wantLeafTasks = 0;
+    uint64_t wantShadeTasks = 0, wantLeafTasks = 0, wantPathRays = 0;
+    // What completed frames of this scene held at most, per pixel: shade tasks, leaf tasks, rays of one path round.  Until a frame
+    // has completed the buffers are sized for the worst case the pipeline accepts; afterwards for half as much again as was seen
+    // (a frame that needs more reports RT_ERR_AGAIN and the buffers grow).
+    // (kept per description of the frame - features and depth - since one scene may be rendered in very different ways)
+    struct SeenQueues {
+        double shade = -1.0, leaf = -1.0, rays = -1.0;
+    };
+    std::unordered_map<uint64_t, SeenQueues> seenQueues;
     std::vector<struct Workspace*> workspaces; // per-frame buffers, one set per stream that frames are queued on (see workspace_for)
     uint64_t useCounter = 0;
     int numCUs = 256;
@@ -125,6 +136,7 @@ struct rt_scene {
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
                                     // RT_AMD_NO_BATCH: one child per round; at most 5)
     bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
+    bool fullQueues = false; // RT_AMD_FULL_QUEUES: frame buffers stay sized for the worst case whatever earlier frames held
     bool noShadowBound = false;     // RT_AMD_NO_SHADOW_BOUND: shadow rays are traced to their closest hit like every other ray
     bool packets = true;            // the camera rays (the path stage's first round) are traced as packets of 64, one stack per wave
                                     // (RT_AMD_PACKETS=0: one by one like every other stage)
@@ -1991,6 +2003,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (const char* e = getenv("RT_AMD_BATCH_WINDOW")) s->batchWindow = (uint32_t)std::min(5, std::max(0, atoi(e)));
     if (getenv("RT_AMD_NO_BATCH")) s->batchWindow = 0;
     s->noPlan = getenv("RT_AMD_NO_PLAN") != nullptr, s->scatter = getenv("RT_AMD_SCATTER") != nullptr;
+    s->fullQueues = getenv("RT_AMD_FULL_QUEUES") != nullptr;
     s->verbose = getenv("RT_AMD_VERBOSE") != nullptr;
     if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
@@ -2371,8 +2384,25 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
     uint64_t want = (uint64_t)nWork * 8u;
     if (want < (1u << 20)) want = 1u << 20;
-    const uint64_t wantShade = std::min<uint64_t>(std::max(want, scene->wantShadeTasks), kMaxQueueTasks);
-    const uint64_t wantLeaf = std::min<uint64_t>(std::max(want, scene->wantLeafTasks), kMaxQueueTasks);
+    uint64_t cfgKey = 1469598103934665603ull; // FNV-1a over what decides how many tasks and rays a pixel gives rise to
+    {
+        auto mix = [&](const void* p, size_t n) {
+            const unsigned char* b = static_cast<const unsigned char*>(p);
+            for (size_t i = 0; i < n; i++) cfgKey = (cfgKey ^ b[i]) * 1099511628211ull;
+        };
+        const int32_t depth = startDepth; // (the flags change how rays are traced and counted, not which rays and tasks there are)
+        mix(&depth, sizeof(depth)), mix(features, sizeof(*features));
+    }
+    w.lastCfg = cfgKey;
+    rt_scene::SeenQueues held;
+    if (!scene->fullQueues) {
+        const auto it = scene->seenQueues.find(cfgKey);
+        if (it != scene->seenQueues.end()) held = it->second;
+    }
+    const bool seen = held.shade >= 0.0;
+    auto sized_for = [&](const double perPixel) { return (uint64_t)(perPixel * 1.5 * (double)nWork) + 65536u; };
+    const uint64_t wantShade = std::min<uint64_t>(std::max(seen ? sized_for(held.shade) : want, scene->wantShadeTasks), kMaxQueueTasks);
+    const uint64_t wantLeaf = std::min<uint64_t>(std::max(seen ? sized_for(held.leaf) : want, scene->wantLeafTasks), kMaxQueueTasks);
     if (w.shadeCap < wantShade) {
         (void)hipFree(w.d_shadeQ);
         w.d_shadeQ = nullptr, w.shadeCap = 0;
@@ -2397,7 +2427,11 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
             batchRays = batchWindow * (batchWindow + 1) / 2;
         }
     }
-    const size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
+    // rays of one round: every state's largest batch at worst; a round of a completed frame tells what to expect (never fewer than
+    // one ray per pixel: the camera's)
+    size_t pathRaysWanted = (size_t)nWork * (batchRays ? batchRays : 1u);
+    if (seen && held.rays >= 0.0) pathRaysWanted = std::min<size_t>(pathRaysWanted, std::max<size_t>(nWork, sized_for(held.rays)));
+    pathRaysWanted = std::max<size_t>(pathRaysWanted, std::min<size_t>(scene->wantPathRays, (size_t)nWork * (batchRays ? batchRays : 1u)));
     // path states: the rounds keep 64-byte headers here and the loop frames / pass records in arrays of their own; a persistent
     // launch keeps a state's header, frames and pass records together (kStateDwords)
     const uint32_t stateStride = usePath ? (uint32_t)kStateDwords : 16u;
@@ -2407,17 +2441,20 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_states), (size_t)nWork * stateStride * sizeof(float)));
         w.stateWords = (size_t)nWork * stateStride;
     }
-    if (!usePath && w.frameStates < nWork) {
+    // a loop is left pending at the rayDepth of its hit: startDepth at the least, one short of the depth limit at the most
+    const int firstLevel = std::min(std::max(startDepth, 0), RT_MAX_RAY_DEPTH - 1);
+    const size_t levelStates = (size_t)nWork * (size_t)(RT_MAX_RAY_DEPTH - firstLevel);
+    if (!usePath && w.frameStates < levelStates) {
         (void)hipFree(w.d_frames);
         w.d_frames = nullptr, w.frameStates = 0;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_frames), (size_t)nWork * RT_MAX_RAY_DEPTH * kFrameDwords * sizeof(float)));
-        w.frameStates = nWork;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_frames), levelStates * kFrameDwords * sizeof(float)));
+        w.frameStates = levelStates;
     }
-    if (!usePath && features->enableTransparency && w.passStates < nWork) {
+    if (!usePath && features->enableTransparency && w.passStates < levelStates) {
         (void)hipFree(w.d_passes);
         w.d_passes = nullptr, w.passStates = 0;
-        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_passes), (size_t)nWork * RT_MAX_RAY_DEPTH * kPassDwords * sizeof(float)));
-        w.passStates = nWork;
+        RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_passes), levelStates * kPassDwords * sizeof(float)));
+        w.passStates = levelStates;
     }
     if (w.stateCap < nWork) {
         (void)hipFree(w.d_active[0]), (void)hipFree(w.d_active[1]);
@@ -2544,7 +2581,10 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     P.shadeCap = w.shadeCap, P.leafCap = w.leafCap;
     P.lightDraws = lightDraws;
     P.states = w.d_states, P.stateStride = stateStride;
-    P.frameBase = w.d_frames, P.passBase = features->enableTransparency ? w.d_passes : nullptr, P.stateCap = nWork;
+    // (addressed by rayDepth: the levels below firstLevel are never touched and have no storage)
+    P.frameBase = w.d_frames ? w.d_frames - (size_t)firstLevel * nWork * kFrameDwords : nullptr;
+    P.passBase = (features->enableTransparency && w.d_passes) ? w.d_passes - (size_t)firstLevel * nWork * kPassDwords : nullptr;
+    P.stateCap = nWork;
     P.pathRays = static_cast<RayRec*>(w.d_pathRays[0]), P.pathRaysIn = nullptr;
     P.rayCap = (uint32_t)(w.pathRayCap > 0xfffffff0ull ? 0xfffffff0ull : w.pathRayCap);
     P.batchRays = batchRays, P.batchWindow = batchWindow;
@@ -2565,6 +2605,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
     const bool planned = !countRef && key == scene->planKey && scene->roundRays.size() == rounds && !scene->noPlan;
     w.lastKey = key, w.lastRounds = usePath ? 0u : rounds;
+    w.lastWork = nWork;
 
     TraceParams T;
     T.S = scene->view;
@@ -3061,6 +3102,14 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
         // (a sequence rendered frame by frame: the fullest queues any of its frames had)
         q[0] = (uint32_t)std::max<unsigned long long>(q[0], carried[S_QMAX_SHADE - S_COUNT]);
         q[1] = (uint32_t)std::max<unsigned long long>(q[1], carried[S_QMAX_LEAF - S_COUNT]);
+        if (scene->verbose)
+            fprintf(stderr, "rt_amd: task queues: %u shade tasks of %u, %u leaf tasks of %u, for %u pixels; path rays held %llu\n", q[0], w.shadeCap, q[1],
+                    w.leafCap, w.lastWork, (unsigned long long)w.pathRayCap);
+        if (w.lastWork) {
+            rt_scene::SeenQueues& held = scene->seenQueues[w.lastCfg];
+            held.shade = std::max(held.shade, (double)q[0] / (double)w.lastWork);
+            held.leaf = std::max(held.leaf, (double)q[1] / (double)w.lastWork);
+        }
         if (q[0] > w.shadeCap || q[1] > w.leafCap) {
             // the next frame gets queues of the size this one asked for and a quarter more
             const bool canGrow = (q[0] > w.shadeCap && w.shadeCap < kMaxQueueTasks) || (q[1] > w.leafCap && w.leafCap < kMaxQueueTasks);
@@ -3073,6 +3122,25 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
                           canGrow ? "the queues grow with the next rt_render of this scene: render the frame again"
                                   : "render with RT_RENDER_SERIAL or in smaller regions");
             return canGrow ? RT_ERR_AGAIN : RT_ERR_LIMIT;
+        }
+    }
+    std::vector<uint32_t> roundRays; // rays of the path rounds (the counters keep counting past the buffer's capacity)
+    if (w.lastWasWavefront && w.lastRounds) {
+        const uint32_t n = w.lastRounds;
+        roundRays.assign(n, 0u);
+        RT_HIP(hipMemcpy(&roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
+        if (n > 1) RT_HIP(hipMemcpy(&roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t most = 0;
+        for (uint32_t v : roundRays) most = std::max(most, v);
+        if (w.lastWork) {
+            rt_scene::SeenQueues& held = scene->seenQueues[w.lastCfg];
+            held.rays = std::max(held.rays, (double)most / (double)w.lastWork);
+        }
+        if (most > w.pathRayCap) { // (sized from what earlier frames needed: this one needs more)
+            scene->wantPathRays = std::max<uint64_t>(scene->wantPathRays, (uint64_t)most + most / 4);
+            rt::set_error("a path round held %u rays for %llu places: the frame is incomplete; the buffers grow with the next rt_render of this "
+                          "scene: render the frame again", most, (unsigned long long)w.pathRayCap);
+            return RT_ERR_AGAIN;
         }
     }
     if (h[S_DROPPED]) {
@@ -3115,10 +3183,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     }
     if (w.lastWasWavefront && w.lastRounds) { // the next frame's plan
         const uint32_t n = w.lastRounds;
-        std::vector<uint32_t>& roundRays = scene->roundRays;
-        roundRays.assign(n, 0u);
-        RT_HIP(hipMemcpy(&roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
-        if (n > 1) RT_HIP(hipMemcpy(&roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        scene->roundRays = roundRays;
         scene->planKey = w.lastKey;
         if (scene->verbose) { // rays traced by the path rounds (candidate batches included), round by round
             unsigned long long sum = 0;
