@@ -457,6 +457,47 @@ def test_a_sequence_rendered_frame_by_frame_reports_an_overflow_of_any_of_its_fr
     assert st.rays == rays and np.abs(got[1]).max() > 0  # the far frame sees the model
 
 
+def test_buffers_sized_by_earlier_frames_grow_for_a_frame_that_needs_more():
+    """A scene's frame buffers are sized by what its completed frames held.  A first frame from far away (a few pixels of
+    model) leaves little; the same features from close up, on a stream whose buffers are allocated after that, need many times
+    the tasks and rays: rt_sync must say RT_ERR_AGAIN, the buffers must grow, and the frame rendered again must be the frame a
+    fresh scene renders (whose first frame is given room for the worst case)."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.dragon_standin(n_u=120, n_v=24)
+    fg, _ = both_features(enableGlossyReflection=1, numGlossySamples=4)
+    W, H = 640, 360
+    far, near = both_cameras(W, H, dist=60.0)[0], both_cameras(W, H, dist=1.6)[0]
+    fresh = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    want = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    fresh.render_device(near, fg, W, H, 2, want.data_ptr(), stream=0)
+    want_stats = fresh.sync(0)
+    g = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    g.render_device(far, fg, W, H, 2, frame.data_ptr(), stream=0)
+    g.sync(0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g.render_device(near, fg, W, H, 2, frame.data_ptr(), stream=side.cuda_stream)
+    with pytest.raises(api.RtError) as e:
+        g.sync(side.cuda_stream)
+    assert e.value.code == api.RT_ERR_AGAIN and "grow" in str(e.value)
+    for attempt in range(4):
+        g.render_device(near, fg, W, H, 2, frame.data_ptr(), stream=side.cuda_stream)
+        try:
+            st = g.sync(side.cuda_stream)
+            break
+        except api.RtError as again:
+            assert again.code == api.RT_ERR_AGAIN and attempt < 3
+    assert st.rays == want_stats.rays and st.pipeline == api.RT_PIPELINE_ROUNDS
+    assert torch.equal(frame, want)
+    # the blocking entry point renders again by itself
+    g2 = api.Scene.from_triangles(sc["prims"], sc["materials"], sc["lights"], sc["spheres"])
+    g2.render_image(far, fg, W, H, start_depth=2, want_ids=False)
+    g2.trim()  # the next allocation is sized by the far frame
+    r = g2.render_image(near, fg, W, H, start_depth=2, want_ids=False)
+    assert np.array_equal(r["rgb"].view(np.uint32), want.cpu().numpy().view(np.uint32)) and r["stats"].rays == want_stats.rays
+
+
 def test_frames_on_several_streams_overlap_without_mixing():
     """Frames of one scene queued on different streams run on buffers of their own: five cameras on five streams at once
     (more streams than the scene keeps buffer sets, so one set is taken over) give the frames and ray counts of the same
