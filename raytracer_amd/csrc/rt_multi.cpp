@@ -185,7 +185,14 @@ int rt_render_images_multi(rt_scene* const* scenes, int nScenes, const rt_camera
                     (void)hipGetLastError();
                 }
             }
-            RT_MULTI_HIP(hipStreamCreateWithFlags(&me.renderStream, hipStreamNonBlocking));
+            { // frames are queued on a stream the scene owns: the scene keeps frame buffers per stream for as long as it lives
+                void* own = nullptr;
+                if (rt_scene_stream(me.scene, 2, &own) != RT_OK) {
+                    me.status = RT_ERR_HIP, me.message = rt_last_error();
+                    return false;
+                }
+                me.renderStream = static_cast<hipStream_t>(own);
+            }
             RT_MULTI_HIP(hipStreamCreateWithFlags(&me.pullStream, hipStreamNonBlocking));
             for (int b = 0; b < 2; b++) {
                 RT_MULTI_HIP(hipMalloc(reinterpret_cast<void**>(&me.d_frames[b]), frameBytes * (size_t)K));
@@ -292,7 +299,7 @@ int rt_render_images_multi(rt_scene* const* scenes, int nScenes, const rt_camera
         (void)hipSetDevice(p.device);
         // (a failed participant broke the meeting: the others may have stopped short of their last wait)
         if (p.pullStream) (void)hipStreamSynchronize(p.pullStream), (void)hipStreamDestroy(p.pullStream);
-        if (p.renderStream) (void)hipStreamSynchronize(p.renderStream), (void)hipStreamDestroy(p.renderStream);
+        if (p.renderStream) (void)hipStreamSynchronize(p.renderStream); // (the scene's own stream: it stays)
         (void)hipFree(p.d_frames[0]), (void)hipFree(p.d_frames[1]), (void)hipFree(p.d_scratch);
         if (p.h_stage) (void)hipHostFree(p.h_stage);
         if (p.status != RT_OK && rc == RT_OK) rc = p.status, message = p.message;
