@@ -136,6 +136,7 @@ struct rt_scene {
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
                                     // RT_AMD_NO_BATCH: one child per round; at most 5)
     bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
+    bool groupNode4 = false; // RT_AMD_GROUP_NODE4: group launches in the query tree walk its 4-wide form
     bool fullQueues = false; // RT_AMD_FULL_QUEUES: frame buffers stay sized for the worst case whatever earlier frames held
     bool noShadowBound = false;     // RT_AMD_NO_SHADOW_BOUND: shadow rays are traced to their closest hit like every other ray
     bool packets = true;            // the camera rays (the path stage's first round) are traced as packets of 64, one stack per wave
@@ -2004,6 +2005,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (getenv("RT_AMD_NO_BATCH")) s->batchWindow = 0;
     s->noPlan = getenv("RT_AMD_NO_PLAN") != nullptr, s->scatter = getenv("RT_AMD_SCATTER") != nullptr;
     s->fullQueues = getenv("RT_AMD_FULL_QUEUES") != nullptr;
+    if (const char* e = getenv("RT_AMD_GROUP_NODE4")) s->groupNode4 = atoi(e) != 0;
     s->verbose = getenv("RT_AMD_VERBOSE") != nullptr;
     if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
@@ -2630,6 +2632,13 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         T.S = query ? scene->queryView : scene->view;
         if (query) { // only with culling, without counters, with 8- or 16-lane groups
             const int qreserve = (int)scene->queryDepth + 2;
+            // (RT_AMD_GROUP_NODE4) eight lanes per ray in the tree's 4-wide form, where its stack bound fits the group's stack
+            const int qreserve4 = 3 * ((int)scene->queryDepth4 + 1) + 3;
+            if (scene->groupNode4 && groupLanes == 8 && !count && !scene->quadTrace && qreserve4 + 4 <= GroupLayout<8, false>::kQ) {
+                if (anyHit) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve4);
+                else hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true, false, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve4);
+                return;
+            }
             if (anyHit && !scene->quadTrace) {
                 if (count) {
                     if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, true, 8, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);

@@ -1679,6 +1679,60 @@ __device__ __forceinline__ void group_node_step(const SceneView& S, GroupLane& T
     T.lq = T.lq + nFarL + __popc(mNearL);
 }
 
+// The same step in the query tree's 4-wide form (query-tree launches only): every lane that pops an entry tests the four
+// boxes of one Node4 (as the one-ray-per-lane kernel does), so a ray's walk is half as many dependent steps deep.  Children
+// go on the stack farthest first - the fourth-nearest children of all lanes, then the third-nearest, ... - so the nearest are
+// popped next.  `reserve` = 3 * (depth of the 4-wide tree) + 3: a pop adds at most three entries net, a step pops only as
+// many entries as leave that room, and a nearly full stack is walked one entry per step, when the growth is bounded by
+// three per level.  Leaves: a pop adds at most four, and a step pops only as many entries as the leaf queue has room for.
+template <bool COUNT, int G>
+__device__ __forceinline__ void group_node4_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const int groupShift,
+                                                 const int reserve, const bool active, TraceCounters& tc)
+{
+    using Lay = GroupLayout<G, false>;
+    constexpr uint32_t kGroupMask = (uint32_t)((1ull << G) - 1ull);
+    uint32_t* const lq = q + Lay::kNodeWords;
+    int n = T.nq < G ? T.nq : G;
+    const int room = (Lay::kQ - reserve - T.nq) / 3;
+    if (n > room) n = room < 1 ? 1 : room;
+    const int leafRoom = (Lay::kLeafQ - T.lq) / 4; // >= 1: the caller checks
+    if (n > leafRoom) n = leafRoom;
+    const int base = T.nq - n;
+    bool take = active && j < n;
+    uint32_t ref = 0;
+    if (take) {
+        const int e = T.nq - 1 - j;
+        ref = q[e];
+        if (__uint_as_float(q[Lay::kEntryOff + e]) > T.cullT) take = false;
+    }
+    Node4Hits h;
+    h.key[0] = h.key[1] = h.key[2] = h.key[3] = kMissKey;
+    h.ref[0] = h.ref[1] = h.ref[2] = h.ref[3] = kEmptyRef;
+    if (take) {
+        if (COUNT) tc.node4++;
+        h = node4_test(S.nodes4 + ref, T.R, T.cullT);
+    }
+    __builtin_amdgcn_wave_barrier(); // every pop of this step precedes its pushes
+    int nq = base, nl = T.lq;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        const bool hit = h.key[k] != kMissKey;
+        const uint32_t cref = hit ? node4_ref(h, h.key[k]) : 0u;
+        const bool isLeaf = hit && (cref & kLeafBit), isNode = hit && !(cref & kLeafBit);
+        const uint32_t mN = (uint32_t)(__ballot(isNode) >> groupShift) & kGroupMask;
+        const uint32_t mL = (uint32_t)(__ballot(isLeaf) >> groupShift) & kGroupMask;
+        const uint32_t below = (1u << j) - 1u;
+        if (isNode) {
+            const int e = nq + __popc(mN & below);
+            q[e] = cref, q[Lay::kEntryOff + e] = __float_as_uint(node4_entry(h.key[k]) - T.R.eps);
+        }
+        if (isLeaf) lq[nl + __popc(mL & below)] = cref;
+        nq += __popc(mN), nl += __popc(mL);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (active) T.nq = nq, T.lq = nl;
+}
+
 // Leaf step for the groups with `active`: pop up to G leaves, test their triangles, refresh the group's best.
 template <bool COUNT, int G, bool QUERY, bool ANY = false>
 __device__ __forceinline__ void group_leaf_step(const SceneView& S, GroupLane& T, uint32_t* const q, const int j, const bool active,
@@ -1758,7 +1812,7 @@ __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane
 
 // trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
 // full stack can always be walked one entry at a time.
-template <bool CULL, bool COUNT, int G, bool QUERY = false, bool ANY = false>
+template <bool CULL, bool COUNT, int G, bool QUERY = false, bool ANY = false, bool N4 = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
     using Lay = GroupLayout<G, !QUERY>;
@@ -1834,8 +1888,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
             // group with work of that kind joins in (nodes only while the leaf queue has room for 2G more).
             const bool needLeaf = has && (T.lq >= G || (T.nq == 0 && T.lq > 0));
             const bool needNode = has && !needLeaf && T.nq > 0;
-            if (__ballot(needNode) != 0ull)
-                group_node_step<CULL, COUNT, G, QUERY>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
+            if (__ballot(needNode) != 0ull) {
+                if (N4) group_node4_step<COUNT, G>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 4 <= Lay::kLeafQ, tc);
+                else group_node_step<CULL, COUNT, G, QUERY>(S, T, q, j, groupShift, reserve, has && T.nq > 0 && T.lq + 2 * G <= Lay::kLeafQ, tc);
+            }
             if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull)
                 group_leaf_step<COUNT, G, QUERY, ANY>(S, T, q, j, has && T.lq > 0, tc);
             const bool done = has && T.nq == 0 && T.lq == 0;

@@ -704,7 +704,8 @@ def test_unnested_caller_tree_is_walked_as_given():
                                    dict(RT_AMD_PATH_MODE="2", RT_AMD_PATH_QUADS="2", RT_AMD_ADVANCE_AT="4"), dict(RT_AMD_QUAD_TRACE="1"),
                                    dict(RT_AMD_NO_SHADOW_BOUND="1"), dict(RT_AMD_NO_SHADOW_BOUND="1", RT_AMD_T1="1", RT_AMD_QBUDGET="2"),
                                    dict(RT_AMD_T1="1", RT_AMD_QBUDGET="1"), dict(RT_AMD_LARGE_FROM="1"), dict(RT_AMD_LARGE_FROM="1", RT_AMD_T1="1"),
-                                   dict(RT_AMD_PACKETS="1"), dict(RT_AMD_PACKETS="0")])
+                                   dict(RT_AMD_PACKETS="1"), dict(RT_AMD_PACKETS="0"), dict(RT_AMD_GROUP_NODE4="1"),
+                                   dict(RT_AMD_GROUP_NODE4="1", RT_AMD_T1="1", RT_AMD_QBUDGET="2")])
 def test_tuning_knobs_change_nothing(knobs, monkeypatch):
     """Every schedule the tuning knobs select (one ray per lane with rays handed over after a few steps, other group
     widths, no candidate batches, another query tree, the path stage as one persistent launch per pixel group, lane or
