@@ -71,6 +71,8 @@ struct Workspace {
     uint64_t lastKey = 0; // what shaped the rounds of the frame last queued here
     uint32_t lastRounds = 0;
     uint32_t lastWork = 0; // pixels (of all its frames) of the last wavefront sequence
+    unsigned long long* d_waveTimes = nullptr; // RT_AMD_WAVE_TIMES: start / end clock of every wave of one round's group launch
+    uint32_t waveTimesWaves = 0;
     uint64_t lastCfg = 0;  // ... and the description its queue sizes are remembered under (rt_scene::seenQueues)
 };
 
@@ -136,6 +138,7 @@ struct rt_scene {
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
                                     // RT_AMD_NO_BATCH: one child per round; at most 5)
     bool noPlan = false, scatter = false, verbose = false; // RT_AMD_NO_PLAN, RT_AMD_SCATTER, RT_AMD_VERBOSE (read once, at scene creation)
+    int waveTimesRound = -1; // RT_AMD_WAVE_TIMES=<round>: record when the waves of that round's group launch start and end (printed by rt_sync with RT_AMD_VERBOSE)
     bool groupNode4 = false; // RT_AMD_GROUP_NODE4: group launches in the query tree walk its 4-wide form
     bool fullQueues = false; // RT_AMD_FULL_QUEUES: frame buffers stay sized for the worst case whatever earlier frames held
     bool noShadowBound = false;     // RT_AMD_NO_SHADOW_BOUND: shadow rays are traced to their closest hit like every other ray
@@ -1728,7 +1731,7 @@ void free_workspace(Workspace* w)
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
     (void)hipFree(w->d_hits), (void)hipFree(w->d_shadowRays), (void)hipFree(w->d_longList), (void)hipFree(w->d_longList2), (void)hipFree(w->d_fallList);
-    (void)hipFree(w->d_orderKeys), (void)hipFree(w->d_order), (void)hipFree(w->d_orderHist);
+    (void)hipFree(w->d_orderKeys), (void)hipFree(w->d_order), (void)hipFree(w->d_orderHist), (void)hipFree(w->d_waveTimes);
     delete w;
 }
 
@@ -2006,6 +2009,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     s->noPlan = getenv("RT_AMD_NO_PLAN") != nullptr, s->scatter = getenv("RT_AMD_SCATTER") != nullptr;
     s->fullQueues = getenv("RT_AMD_FULL_QUEUES") != nullptr;
     if (const char* e = getenv("RT_AMD_GROUP_NODE4")) s->groupNode4 = atoi(e) != 0;
+    if (const char* e = getenv("RT_AMD_WAVE_TIMES")) s->waveTimesRound = atoi(e);
     s->verbose = getenv("RT_AMD_VERBOSE") != nullptr;
     if (const char* e = getenv("RT_AMD_WIDE_BELOW")) s->wideBelow = (uint32_t)atoi(e);
     if (const char* e = getenv("RT_AMD_BUDGET")) s->stepBudget = (uint32_t)atoi(e);
@@ -2614,6 +2618,8 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     T.hits = static_cast<HitRec*>(w.d_hits);
     T.stats = w.d_stats;
     T.useBvh = features->enableAccelStructure ? 1u : 0u;
+    T.waveTimes = nullptr;
+    int roundNow = 0; // the path round being launched (0: another stage)
     uint32_t nextFetch = 2 * kMaxRounds;
     uint32_t* const rayCounts = w.d_roundCounts + kMaxRounds;
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
@@ -2756,7 +2762,20 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         const bool wide = smallRound && useQuery && scene->groupLanes == 8 && expected < scene->wideBelow;
         const uint32_t rpb = wide ? groupRaysPerBlock / 2 : groupRaysPerBlock;
         if (smallRound) gridNow = std::min(wide ? 2 * groupGrid : groupGrid, std::max(256u, ((2u * expected + rpb - 1) / rpb + 7u) & ~7u));
+        if (roundNow != 0 && roundNow == scene->waveTimesRound) { // diagnostics: this launch's waves note their start and end
+            const uint32_t waves = gridNow * (kBlock / 64);
+            if (w.waveTimesWaves < waves) {
+                (void)hipFree(w.d_waveTimes);
+                w.d_waveTimes = nullptr, w.waveTimesWaves = 0;
+                if (hipMalloc(reinterpret_cast<void**>(&w.d_waveTimes), (size_t)waves * 16) == hipSuccess) w.waveTimesWaves = waves;
+            }
+            if (w.d_waveTimes) {
+                (void)hipMemsetAsync(w.d_waveTimes, 0, (size_t)w.waveTimesWaves * 16, st);
+                T.waveTimes = w.d_waveTimes;
+            }
+        }
         launch_one(wide ? 16u : scene->groupLanes, useQuery);
+        T.waveTimes = nullptr;
         gridNow = groupGrid;
         if (budget) { // the handed-over rays (none unless the first launch ran)
             T.runLo = 0, T.runHi = 0xffffffffu;
@@ -2897,9 +2916,11 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         // other schedule up to half as many rays again, should this frame's round be larger)
         const bool smallRound = planned && scene->roundRays[r - 1] < laneModeAbove;
         packetRound = r == 1 && scene->packets && features->numPixelSamples <= 1;
+        roundNow = (int)r;
         launch_trace(w.d_pathRays[(r - 1) & 1], sizeof(RayRec), r == 1 ? w.d_roundCounts : rayCounts + (r - 1), 0, P.rayCap, 1, smallRound,
                      smallRound ? scene->roundRays[r - 1] : 0u);
         packetRound = false;
+        roundNow = 0;
         P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);
         P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
@@ -3179,6 +3200,26 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             fprintf(stderr, " %u", v);
         }
         fprintf(stderr, "\n");
+    }
+    if (w.lastWasWavefront && scene->verbose && w.d_waveTimes && w.waveTimesWaves) {
+        std::vector<unsigned long long> tv((size_t)w.waveTimesWaves * 2);
+        RT_HIP(hipMemcpy(tv.data(), w.d_waveTimes, tv.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull, last = 0;
+        for (uint32_t i = 0; i < w.waveTimesWaves; i++)
+            if (tv[2 * i + 1]) first = std::min(first, tv[2 * i]), last = std::max(last, tv[2 * i + 1]);
+        std::vector<double> ends, durs;
+        for (uint32_t i = 0; i < w.waveTimesWaves; i++)
+            if (tv[2 * i + 1]) ends.push_back((double)(tv[2 * i + 1] - first)), durs.push_back((double)(tv[2 * i + 1] - tv[2 * i]));
+        std::sort(ends.begin(), ends.end()), std::sort(durs.begin(), durs.end());
+        if (!ends.empty()) {
+            // (the clock ticks at 100 MHz)
+            fprintf(stderr, "rt_amd: round %d group launch: %zu waves over %.1f us; waves ended by (us), percentiles 10 25 50 75 90 95 99 100:", scene->waveTimesRound,
+                    ends.size(), (double)(last - first) / 100.0);
+            for (double q : { 0.10, 0.25, 0.50, 0.75, 0.90, 0.95, 0.99, 1.0 }) fprintf(stderr, " %.1f", ends[std::min(ends.size() - 1, (size_t)(q * ends.size()))] / 100.0);
+            fprintf(stderr, "; wave lifetimes (us), same percentiles:");
+            for (double q : { 0.10, 0.25, 0.50, 0.75, 0.90, 0.95, 0.99, 1.0 }) fprintf(stderr, " %.1f", durs[std::min(durs.size() - 1, (size_t)(q * durs.size()))] / 100.0);
+            fprintf(stderr, "\n");
+        }
     }
     if (w.lastWasWavefront && scene->verbose && !w.longSlots.empty()) {
         const uint32_t lo = w.longSlots.front(), hi = w.longSlots.back();

@@ -245,6 +245,7 @@ struct TraceParams {
     uint32_t* fallCount;      // appended here and traced again in the reference's tree
     unsigned long long* stats;
     uint32_t useBvh;
+    unsigned long long* waveTimes; // diagnostics (RT_AMD_WAVE_TIMES): per wave of a group launch, the clock at its start and at its end (null: off)
 };
 
 // One closest-hit query in flight on a lane.
@@ -1839,6 +1840,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
     T.bestT = T.cullT = 0.0f, T.bestKey = 0, T.bestTri = kNoHit, T.nq = T.lq = 0;
     T.tieT = -1.0f;
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) / G >= total) return; // nothing for this wave, now or later
+    const unsigned long long waveStart = P.waveTimes ? wall_clock64() : 0ull;
     for (;;) {
         const unsigned long long idle = __ballot(!has && j == 0);
         if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd)) {
@@ -1909,6 +1911,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) voi
                 }
             }
         }
+    }
+    if (P.waveTimes && lane == 0) {
+        const size_t wv = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+        P.waveTimes[2 * wv] = waveStart, P.waveTimes[2 * wv + 1] = wall_clock64();
     }
     if (COUNT) flush_counters(P.stats, lane, 0, 0, 0, tc, 0, 0);
 }
