@@ -1813,8 +1813,11 @@ __device__ __forceinline__ bool group_finish_query(const SceneView& S, GroupLane
 
 // trace_kernel with G lanes per ray.  `reserve` = tree depth + 2: the stack room kept free so that a nearly
 // full stack can always be walked one entry at a time.
+#ifndef RT_GROUP_WAVES
+#define RT_GROUP_WAVES 4 // waves per SIMD the group kernel is compiled for (5: 96 registers, 49 spilled, a frame 18 % slower)
+#endif
 template <bool CULL, bool COUNT, int G, bool QUERY = false, bool ANY = false, bool N4 = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) void group_trace_kernel(const TraceParams P, const int reserve)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_GROUP_WAVES))) void group_trace_kernel(const TraceParams P, const int reserve)
 {
     using Lay = GroupLayout<G, !QUERY>;
     __shared__ uint32_t s_q[Lay::kWords];
