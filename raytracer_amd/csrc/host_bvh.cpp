@@ -1,13 +1,16 @@
 // Host side of librt_amd.so: BVH construction in the reference's layout, flattening into the GPU
 // layout, camera set-up.  Pure CPU code; runs once per scene, never per ray.
 #include "rt_types.h"
+#include "rt_tri.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <utility>
 
 namespace rt {
@@ -200,37 +203,7 @@ void countLevelsAndLeaves(rt_bvh& b) // buildNumLevels / buildNumLeaves (src/bvh
 // ---------------------------------------------------------------------------------------------
 // Flattening: reference nodes()/primitives() -> NodePair / TriPlane / TriEdges / TriAttr
 // ---------------------------------------------------------------------------------------------
-static void precomputeTriangle(const RefPrimitive& p, uint32_t primId, TriPlane& pl, TriEdges& ed, TriAttr& at)
-{
-    const vec3 v0 = load3(p.v0.position), v1 = load3(p.v1.position), v2 = load3(p.v2.position);
-    // trianglePlane of the reference's intersect archive == the geometric normal of updateHitInfo
-    vec3 n = cross(v1 - v0, v2 - v0);
-    n = n * (1.0f / sqrtf(dot(n, n)));
-    pl.n[0] = n.x, pl.n[1] = n.y, pl.n[2] = n.z;
-    pl.D = dot(v0, n);
-    // pointInTriangle edge vectors
-    const vec3 c0 = cross(v2 - v0, n), c1 = cross(v0 - v1, n), c2 = cross(v1 - v2, n);
-    ed.v0[0] = v0.x, ed.v0[1] = v0.y, ed.v0[2] = v0.z, ed.c0x = c0.x;
-    ed.c0y = c0.y, ed.c0z = c0.z, ed.v1x = v1.x, ed.v1y = v1.y;
-    ed.v1z = v1.z, ed.c1[0] = c1.x, ed.c1[1] = c1.y, ed.c1[2] = c1.z;
-    ed.v2[0] = v2.x, ed.v2[1] = v2.y, ed.v2[2] = v2.z, ed.c2x = c2.x;
-    ed.c2y = c2.y, ed.c2z = c2.z, ed.pad[0] = ed.pad[1] = 0.0f;
-    // computeBarycentricCoord constants (src/interpolate.cpp:13-23)
-    const vec3 first = v1 - v0, second = v2 - v0;
-    at.primId = primId;
-    at.meshID = p.meshID;
-    at.d00 = dot(first, first);
-    at.d01 = dot(first, second);
-    at.d11 = dot(second, second);
-    at.denom = at.d00 * at.d11 - at.d01 * at.d01;
-    memcpy(at.n0, p.v0.normal, 12);
-    memcpy(at.n1, p.v1.normal, 12);
-    memcpy(at.n2, p.v2.normal, 12);
-    memcpy(at.uv0, p.v0.texCoord, 8);
-    memcpy(at.uv1, p.v1.texCoord, 8);
-    memcpy(at.uv2, p.v2.texCoord, 8);
-    at.pad[0] = at.pad[1] = at.pad[2] = 0.0f;
-}
+static void precomputeTriangle(const RefPrimitive& p, uint32_t primId, TriPlane& pl, TriEdges& ed, TriAttr& at) { precompute_triangle(p, primId, pl, ed, at); }
 
 namespace {
 struct Flattener {
@@ -246,6 +219,7 @@ struct Flattener {
     int status = RT_OK;
     std::vector<uint8_t> seen;
     std::vector<std::pair<uint32_t, uint32_t>> arrayPos; // (position in primitives(), compact index)
+    std::vector<uint8_t> leafOf;                         // one entry per compact triangle met so far
 
     uint32_t fail(int code)
     {
@@ -285,31 +259,19 @@ struct Flattener {
                 snprintf(msg, msgLen, "flatten: leaf %u range [%u,%u) exceeds %u primitives", i, off, off + cnt, nPrims);
                 return fail(RT_ERR_INVALID);
             }
-            const uint32_t first = uint32_t(out.triPlane.size());
+            const uint32_t first = uint32_t(leafOf.size());
             if (uint64_t(first) + cnt > kRefOffsetMask) {
                 snprintf(msg, msgLen, "flatten: more than %u triangles", kRefOffsetMask);
                 return fail(RT_ERR_LIMIT);
             }
+            // (the walk does not touch the primitives themselves - 100 bytes apart, a cache miss each: their mesh indices are
+            // checked with the per-triangle work that follows the walk, on several threads)
+            const float box[6] = { n.lower[0], n.lower[1], n.lower[2], n.upper[0], n.upper[1], n.upper[2] };
             for (uint32_t k = 0; k < cnt; k++) {
-                const RefPrimitive& p = prims[off + k];
-                if (p.meshID >= nMaterials) {
-                    snprintf(msg, msgLen, "flatten: primitive %u has meshID %u but only %u materials", off + k, p.meshID, nMaterials);
-                    return fail(RT_ERR_INVALID);
-                }
-                TriPlane pl;
-                TriEdges ed;
-                TriAttr at;
-                precomputeTriangle(p, primIds ? primIds[off + k] : off + k, pl, ed, at);
-                arrayPos.push_back({ off + k, uint32_t(out.triPlane.size()) });
-                out.leafBox.insert(out.leafBox.end(), n.lower, n.lower + 3);
-                out.leafBox.insert(out.leafBox.end(), n.upper, n.upper + 3);
+                arrayPos.push_back({ off + k, uint32_t(leafOf.size()) });
+                leafOf.push_back(0); // (one entry per compact triangle: the walk only counts them; their records are computed afterwards)
+                out.leafBox.insert(out.leafBox.end(), box, box + 6);
                 out.leafRoute.push_back(route);
-                for (const RefVertex* v : { &p.v0, &p.v1, &p.v2 })
-                    for (int a = 0; a < 3; a++)
-                        if (!(v->position[a] >= nodes[0].lower[a] && v->position[a] <= nodes[0].upper[a])) out.nested = false;
-                out.triPlane.push_back(pl);
-                out.triEdges.push_back(ed);
-                out.triAttr.push_back(at);
             }
             if (cnt >= kMaxLeafCount) { // (the SAH-binned build leaves spans it cannot split cheaply whole: hundreds of triangles in one leaf)
                 if (out.leafCounts.empty()) out.leafCounts.assign(nPrims, 0u);
@@ -342,7 +304,7 @@ struct Flattener {
 } // namespace
 
 int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,
-            uint32_t nMaterials, FlatScene& out, const char** err)
+            uint32_t nMaterials, FlatScene& out, const char** err, bool records)
 {
     static thread_local char msg[256];
     msg[0] = 0;
@@ -356,13 +318,63 @@ int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, ui
     f.seen.assign(nNodes, 0);
     {
         const size_t guess = nPrims / 2 + 16; // (the reference stores every triangle twice; a caller's tree may not)
-        out.triPlane.reserve(guess), out.triEdges.reserve(guess), out.triAttr.reserve(guess), out.leafRoute.reserve(guess);
+        out.leafRoute.reserve(guess);
         out.leafBox.reserve(6 * guess), out.pairs.reserve(nNodes / 2 + 1), f.arrayPos.reserve(guess);
     }
     memcpy(out.rootLo, nodes[0].lower, 12);
     memcpy(out.rootHi, nodes[0].upper, 12);
+    const bool verbose = getenv("RT_AMD_VERBOSE") != nullptr;
+    const auto tWalk = std::chrono::steady_clock::now();
     out.rootRef = f.visit(0, 1, 1u);
     if (f.status != RT_OK) return f.status;
+    const auto tRecords = std::chrono::steady_clock::now();
+    { // where compact triangle i lies in primitives(), and the index it reports
+        const size_t n = f.arrayPos.size();
+        out.srcPos.resize(n), out.srcPrimId.resize(n);
+        for (size_t i = 0; i < n; i++) out.srcPos[i] = f.arrayPos[i].first, out.srcPrimId[i] = primIds ? primIds[f.arrayPos[i].first] : f.arrayPos[i].first;
+    }
+    { // the triangles' records (when asked for) and whether every vertex lies in the root box: independent of one another
+        const size_t n = f.arrayPos.size();
+        if (records) out.triPlane.resize(n), out.triEdges.resize(n), out.triAttr.resize(n);
+        std::atomic<bool> inside { true }; // every vertex lies in the root box (part of `nested`)
+        std::atomic<uint32_t> badMesh { 0xffffffffu }; // the first primitive (in array order) whose mesh has no material
+        auto fill = [&](size_t lo, size_t hi) {
+            bool in = true;
+            for (size_t i = lo; i < hi; i++) {
+                const uint32_t pos = f.arrayPos[i].first;
+                const RefPrimitive& p = prims[pos];
+                if (p.meshID >= nMaterials) {
+                    uint32_t seen = badMesh.load();
+                    while (pos < seen && !badMesh.compare_exchange_weak(seen, pos)) {}
+                    continue;
+                }
+                for (const RefVertex* v : { &p.v0, &p.v1, &p.v2 })
+                    for (int a = 0; a < 3; a++)
+                        if (!(v->position[a] >= nodes[0].lower[a] && v->position[a] <= nodes[0].upper[a])) in = false;
+                if (records) precomputeTriangle(p, out.srcPrimId[i], out.triPlane[i], out.triEdges[i], out.triAttr[i]);
+            }
+            if (!in) inside.store(false);
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        size_t workers = n < 16384 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+        if (const char* e = getenv("RT_AMD_FLATTEN_THREADS")) workers = std::max(1, atoi(e));
+        if (workers <= 1) {
+            fill(0, n);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t share = (n + workers - 1) / workers;
+            for (size_t k = 1; k < workers; k++) pool.emplace_back(fill, std::min(n, k * share), std::min(n, (k + 1) * share));
+            fill(0, std::min(n, share));
+            for (std::thread& t : pool) t.join();
+        }
+        if (!inside.load()) out.nested = false;
+        if (badMesh.load() != 0xffffffffu) {
+            const uint32_t pos = badMesh.load();
+            snprintf(msg, sizeof(msg), "flatten: primitive %u has meshID %u but only %u materials", pos, prims[pos].meshID, nMaterials);
+            return RT_ERR_INVALID;
+        }
+    }
+    const auto tOrder = std::chrono::steady_clock::now();
     // Brute-force order (enableAccelStructure off, src/bvh.cpp:351-363) = primitives() array order.
     // (every position occurs at most once - a leaf range met twice means a node met twice, which visit refuses - so the sort is a scatter)
     std::vector<uint32_t> atPos(nPrims, 0xffffffffu);
@@ -379,6 +391,11 @@ int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, ui
     } else { // overlapping leaf ranges: positions repeat, keep every occurrence in array order
         std::sort(f.arrayPos.begin(), f.arrayPos.end());
         for (const auto& ap : f.arrayPos) out.bruteOrder.push_back(ap.second);
+    }
+    if (verbose) {
+        const auto tEnd = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "flatten: walk %.2f ms, triangle records %.2f ms, array order %.2f ms\n", ms(tWalk, tRecords), ms(tRecords, tOrder), ms(tOrder, tEnd));
     }
     return RT_OK;
 }
@@ -547,26 +564,41 @@ struct QueryBuilder {
 };
 } // namespace
 
-void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice, bool hostLayouts)
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice, bool hostLayouts, const RefPrimitive* prims, const float* dLo4,
+                      const float* dHi4)
 {
     out = QueryTree {};
-    const uint32_t n = uint32_t(flat.triPlane.size());
+    const uint32_t n = uint32_t(flat.srcPos.size());
     // the proof a query needs rests on nested reference boxes and on slab distances that are exact with reciprocals
     if (n <= 8 || !flat.nested || !flat.fastBounds || (flat.rootRef & kLeafBit)) return;
     QueryBuilder qb;
     if (const char* e = getenv("RT_AMD_QLEAF")) qb.kLeaf = uint32_t(atoi(e));
     if (qb.kLeaf < 1 || qb.kLeaf > 8) qb.kLeaf = 4;
-    qb.lo.resize(n), qb.hi.resize(n), qb.c.resize(n), qb.idx.resize(n);
-    for (uint32_t i = 0; i < n; i++) {
-        const TriEdges& t = flat.triEdges[i];
-        const vec3 v0 = make3(t.v0[0], t.v0[1], t.v0[2]), v1 = make3(t.v1x, t.v1y, t.v1z), v2 = make3(t.v2[0], t.v2[1], t.v2[2]);
-        qb.lo[i] = gmin(gmin(v0, v1), v2), qb.hi[i] = gmax(gmax(v0, v1), v2);
-        qb.c[i] = (qb.lo[i] + qb.hi[i]) * 0.5f;
-    }
+    qb.idx.resize(n);
+    // the triangles' boxes on the host: for the host builder, and for a device build whose caller has not put them on the device
+    auto host_boxes = [&]() {
+        if (!qb.lo.empty()) return true;
+        if (flat.triEdges.size() != n && !prims) return false;
+        qb.lo.resize(n), qb.hi.resize(n), qb.c.resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            vec3 v0, v1, v2;
+            if (flat.triEdges.size() == n) {
+                const TriEdges& t = flat.triEdges[i];
+                v0 = make3(t.v0[0], t.v0[1], t.v0[2]), v1 = make3(t.v1x, t.v1y, t.v1z), v2 = make3(t.v2[0], t.v2[1], t.v2[2]);
+            } else {
+                const RefPrimitive& p = prims[flat.srcPos[i]];
+                v0 = load3(p.v0.position), v1 = load3(p.v1.position), v2 = load3(p.v2.position);
+            }
+            qb.lo[i] = gmin(gmin(v0, v1), v2), qb.hi[i] = gmax(gmax(v0, v1), v2);
+            qb.c[i] = (qb.lo[i] + qb.hi[i]) * 0.5f;
+        }
+        return true;
+    };
     using clock = std::chrono::steady_clock;
     auto ms_since = [](clock::time_point t0) { return std::chrono::duration<float, std::milli>(clock::now() - t0).count(); };
     auto emit = [&](uint32_t root) {
         out.nodes.clear(), out.pairs.clear();
+        out.nodes.reserve(qb.tree.size()), out.pairs.reserve(qb.tree.size()); // (one pair per binary node, at most as many 4-wide nodes)
         out.maxDepth = 0, out.pairDepth = 1; // pairDepth counts levels of nodes as the flattener does: the root is level 1
         out.rootRef = qb.collapse(root, out.nodes, 1, out.maxDepth);
         out.pairRootRef = qb.emitPairs(root, out.pairs, 2, out.pairDepth);
@@ -574,14 +606,20 @@ void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice, bool
     bool built = false;
     if (onDevice) { // the same split rule, one level per launch (query_build.hip)
         const auto t0 = clock::now();
-        std::vector<float> lo4(size_t(n) * 4), hi4(size_t(n) * 4);
-        for (uint32_t i = 0; i < n; i++) {
-            lo4[4 * size_t(i)] = qb.lo[i].x, lo4[4 * size_t(i) + 1] = qb.lo[i].y, lo4[4 * size_t(i) + 2] = qb.lo[i].z, lo4[4 * size_t(i) + 3] = 0.0f;
-            hi4[4 * size_t(i)] = qb.hi[i].x, hi4[4 * size_t(i) + 1] = qb.hi[i].y, hi4[4 * size_t(i) + 2] = qb.hi[i].z, hi4[4 * size_t(i) + 3] = 0.0f;
+        std::vector<float> lo4, hi4;
+        const bool resident = dLo4 && dHi4; // the caller computed the boxes on the device
+        if (!resident && host_boxes()) {
+            lo4.resize(size_t(n) * 4), hi4.resize(size_t(n) * 4);
+            for (uint32_t i = 0; i < n; i++) {
+                lo4[4 * size_t(i)] = qb.lo[i].x, lo4[4 * size_t(i) + 1] = qb.lo[i].y, lo4[4 * size_t(i) + 2] = qb.lo[i].z, lo4[4 * size_t(i) + 3] = 0.0f;
+                hi4[4 * size_t(i)] = qb.hi[i].x, hi4[4 * size_t(i) + 1] = qb.hi[i].y, hi4[4 * size_t(i) + 2] = qb.hi[i].z, hi4[4 * size_t(i) + 3] = 0.0f;
+            }
         }
         std::vector<DeviceBuildNode> nodes;
         uint32_t levels = 0;
-        if (device_build_query_hierarchy(lo4.data(), hi4.data(), n, qb.kLeaf, nodes, qb.idx, levels, &out.deviceKernelMs) && !nodes.empty()) {
+        if ((resident || !lo4.empty())
+            && device_build_query_hierarchy(resident ? dLo4 : lo4.data(), resident ? dHi4 : hi4.data(), resident, n, qb.kLeaf, nodes, qb.idx, levels, &out.deviceKernelMs)
+            && !nodes.empty()) {
             qb.tree.resize(nodes.size());
             for (size_t i = 0; i < nodes.size(); i++) {
                 qb.tree[i].lo = make3(nodes[i].lo[0], nodes[i].lo[1], nodes[i].lo[2]);
@@ -590,12 +628,14 @@ void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice, bool
             }
             out.hierarchyMs = ms_since(t0);
             const auto t1 = clock::now();
+            if (!host_boxes()) return; // (the layouts hold the boxes of the leaves, which the hierarchy does not)
             emit(0);
             out.layoutMs = ms_since(t1);
             built = out.pairDepth <= 48;
             out.builtOnDevice = built;
         }
     }
+    if (!built && !host_boxes()) return; // (no triangle data on the host: the scene does without a query tree)
     for (int attempt = 0; attempt < 2 && !built; attempt++) {
         const auto t0 = clock::now();
         qb.tree.clear();

@@ -27,7 +27,7 @@
 namespace rt {
 namespace {
 
-constexpr int kBuildBlock = 256;
+constexpr int kSmallBlock = 256, kLargeBlock = 1024, kLargeLevels = 6; // levels 0 .. 5 (at most 32 nodes) run with the large workgroup
 constexpr int kBins = 16;
 constexpr int kMaxLevels = 64;
 
@@ -68,8 +68,12 @@ __device__ __forceinline__ int bin_of(const float c, const float c0, const float
     return k < 0 ? 0 : (k >= kBins ? kBins - 1 : k);
 }
 
-__global__ __launch_bounds__(kBuildBlock) void sah_level_kernel(const BuildParams P)
+// BLOCK threads per node: the few nodes of the top levels hold tens of thousands of triangles each and are walked by one
+// workgroup, which is bound by the latency of its gathers - sixteen waves hide four times as much of it as four.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void sah_level_kernel(const BuildParams P)
 {
+    constexpr int kBuildBlock = BLOCK;
     __shared__ uint32_t s_box[12];                 // ordered: box lo[3], box hi[3], centroid lo[3], centroid hi[3]
     __shared__ uint32_t s_binN[3][kBins];
     __shared__ uint32_t s_binLo[3][kBins][3], s_binHi[3][kBins][3];
@@ -255,11 +259,12 @@ __global__ __launch_bounds__(kBuildBlock) void sah_level_kernel(const BuildParam
 
 } // namespace
 
-// Builds the hierarchy over `n` triangle boxes (lo4 / hi4: 4 floats per triangle, the fourth unused) on the current device.
+// Builds the hierarchy over `n` triangle boxes (lo4 / hi4: 4 floats per triangle, the fourth unused; host arrays, or with
+// `resident` arrays already on the current device) on the current device.
 // On success `tree` holds the nodes (node 0 = root; a child is a node index or a leaf reference kLeafBit | count << 25 |
 // first place in `order`), `order` the triangles in leaf order and `depth` the number of node levels.  False when the
 // device cannot be used, the tree came out deeper than 64 levels or an allocation failed: the caller builds on the host.
-bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
+bool device_build_query_hierarchy(const float* lo4, const float* hi4, bool resident, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
                                   std::vector<uint32_t>& order, uint32_t& depth, float* kernelMs)
 {
     bool ok = true;
@@ -274,16 +279,20 @@ bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n
     int devCount = 0;
     if (n <= leafMax || hipGetDeviceCount(&devCount) != hipSuccess || devCount == 0) return false;
     for (uint32_t i = 0; i < n; i++) iota[i] = i;
-    RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dLo), size_t(n) * 16));
-    RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dHi), size_t(n) * 16));
+    if (!resident) {
+        RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dLo), size_t(n) * 16));
+        RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dHi), size_t(n) * 16));
+    }
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dIdx), size_t(n) * 4));
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dScratch), size_t(n) * 4));
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dTree), size_t(maxNodes) * sizeof(DeviceBuildNode)));
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dWork[0]), size_t(maxWork) * sizeof(Work)));
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dWork[1]), size_t(maxWork) * sizeof(Work)));
     RT_BUILD_HIP(hipMalloc(reinterpret_cast<void**>(&dCounters), counters.size() * 4));
-    RT_BUILD_HIP(hipMemcpy(dLo, lo4, size_t(n) * 16, hipMemcpyHostToDevice));
-    RT_BUILD_HIP(hipMemcpy(dHi, hi4, size_t(n) * 16, hipMemcpyHostToDevice));
+    if (!resident) {
+        RT_BUILD_HIP(hipMemcpy(dLo, lo4, size_t(n) * 16, hipMemcpyHostToDevice));
+        RT_BUILD_HIP(hipMemcpy(dHi, hi4, size_t(n) * 16, hipMemcpyHostToDevice));
+    }
     RT_BUILD_HIP(hipMemcpy(dIdx, iota.data(), size_t(n) * 4, hipMemcpyHostToDevice));
     counters[0] = 1, counters[1] = 1; // the root: node 0, the only work item of level 0
     RT_BUILD_HIP(hipMemcpy(dCounters, counters.data(), counters.size() * 4, hipMemcpyHostToDevice));
@@ -296,13 +305,14 @@ bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n
     RT_BUILD_HIP(hipEventRecord(ev0, nullptr));
     for (int level = 0; level < kMaxLevels; level++) {
         BuildParams P;
-        P.lo = dLo, P.hi = dHi, P.idx = dIdx, P.scratch = dScratch, P.tree = dTree;
+        P.lo = resident ? reinterpret_cast<const float4*>(lo4) : dLo, P.hi = resident ? reinterpret_cast<const float4*>(hi4) : dHi, P.idx = dIdx, P.scratch = dScratch, P.tree = dTree;
         P.in = dWork[level & 1], P.out = dWork[(level + 1) & 1];
         P.counters = dCounters;
         P.level = (uint32_t)level, P.leafMax = leafMax, P.maxNodes = maxNodes, P.maxWork = maxWork;
         // a level holds at most 2^level nodes, and never more than there are ranges above the leaf size
         const uint32_t grid = level < 20 ? std::min<uint32_t>(1u << level, maxWork) : maxWork;
-        hipLaunchKernelGGL(sah_level_kernel, dim3(grid), dim3(kBuildBlock), 0, nullptr, P);
+        if (level < kLargeLevels) hipLaunchKernelGGL(sah_level_kernel<kLargeBlock>, dim3(grid), dim3(kLargeBlock), 0, nullptr, P);
+        else hipLaunchKernelGGL(sah_level_kernel<kSmallBlock>, dim3(grid), dim3(kSmallBlock), 0, nullptr, P);
     }
     RT_BUILD_HIP(hipGetLastError());
     RT_BUILD_HIP(hipEventRecord(ev1, nullptr));

@@ -6,6 +6,7 @@
 // and square root, denormals kept.  Expression order follows the reference expression cited at
 // each function because float ties decide which triangle a ray reports.
 #include "rt_types.h"
+#include "rt_tri.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1669,6 +1670,29 @@ __global__ void carry_frame_counts_kernel(const uint32_t* qCount, const uint32_t
     if (fallCount) stats[S_FALL_SUM] += *fallCount;
 }
 
+// rt_scene_create's triangle work, from the caller's primitives() as uploaded: compact triangle i is primitive srcPos[i].
+// The boxes feed the device build of the query tree; the records are the scene's own (precompute_triangle: the host's function).
+__global__ __launch_bounds__(kBlock) void triangle_boxes_kernel(const RefPrimitive* prims, const uint32_t* srcPos, const uint32_t n, float4* lo4, float4* hi4)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const RefPrimitive& p = prims[srcPos[i]];
+    const vec3 v0 = load3(p.v0.position), v1 = load3(p.v1.position), v2 = load3(p.v2.position);
+    const vec3 lo = gmin(gmin(v0, v1), v2), hi = gmax(gmax(v0, v1), v2);
+    lo4[i] = make_float4(lo.x, lo.y, lo.z, 0.0f), hi4[i] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+}
+__global__ __launch_bounds__(kBlock) void triangle_records_kernel(const RefPrimitive* prims, const uint32_t* srcPos, const uint32_t* srcPrimId, const uint32_t n,
+                                                                  TriPlane* plane, TriEdges* edges, TriAttr* attr)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    TriPlane pl;
+    TriEdges ed;
+    TriAttr at;
+    precompute_triangle(prims[srcPos[i]], srcPrimId[i], pl, ed, at);
+    plane[i] = pl, edges[i] = ed, attr[i] = at;
+}
+
 // The triangle records of the query tree: place i of its leaf order holds triangle order[i] of the caller's tree - the plane and
 // edge records copied, and the certificate (the triangle's index, the box of its reference leaf and that leaf's route from
 // the root) put together.  Runs once per scene, after the upload.
@@ -1833,8 +1857,10 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     const auto tStart = clock::now();
     FlatScene flat;
     const char* err = "";
+    // (the triangles' records are computed on the device, from the primitives as they are: RT_AMD_HOST_RECORDS keeps them on the host)
+    const bool deviceRecords = getenv("RT_AMD_HOST_RECORDS") == nullptr && nPrims != 0;
     int rc = flatten(static_cast<const RefNode*>(nodes), nNodes, static_cast<const RefPrimitive*>(prims), nPrims, primIds, nMaterials,
-                     flat, &err);
+                     flat, &err, !deviceRecords);
     if (rc != RT_OK) {
         rt::set_error("%s", err);
         return rc;
@@ -1858,10 +1884,39 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     QueryTree qt;
     // the library's own tree: hierarchy on the device unless RT_AMD_HOST_QUERY_BUILD asks for the host builder
     // (its triangle records are gathered on the device, after the upload)
-    if (!getenv("RT_AMD_NO_QUERY_TREE")) build_query_tree(flat, qt, getenv("RT_AMD_HOST_QUERY_BUILD") == nullptr, false);
+    const size_t nPairs = flat.pairs.size(), nTris = flat.srcPos.size();
+    // the primitives, the compact triangles' places in them and their boxes on the device (released when the scene is up)
+    char* d_temp = nullptr;
+    const RefPrimitive* dPrims = nullptr;
+    const uint32_t *dSrcPos = nullptr, *dSrcPrimId = nullptr;
+    float4 *dLo4 = nullptr, *dHi4 = nullptr;
+    if (deviceRecords && nTris) {
+        const size_t bytes = padded((size_t)nPrims * sizeof(RefPrimitive)) + 2 * padded(nTris * 4) + 2 * padded(nTris * 16);
+        hipError_t te = hipMalloc(reinterpret_cast<void**>(&d_temp), bytes);
+        if (te == hipSuccess) {
+            char* tp = d_temp;
+            dPrims = carve<RefPrimitive>(tp, nPrims), dSrcPos = carve<uint32_t>(tp, nTris), dSrcPrimId = carve<uint32_t>(tp, nTris);
+            dLo4 = const_cast<float4*>(carve<float4>(tp, nTris)), dHi4 = const_cast<float4*>(carve<float4>(tp, nTris));
+            te = hipMemcpy(const_cast<RefPrimitive*>(dPrims), prims, (size_t)nPrims * sizeof(RefPrimitive), hipMemcpyHostToDevice);
+            if (te == hipSuccess) te = hipMemcpy(const_cast<uint32_t*>(dSrcPos), flat.srcPos.data(), nTris * 4, hipMemcpyHostToDevice);
+            if (te == hipSuccess) te = hipMemcpy(const_cast<uint32_t*>(dSrcPrimId), flat.srcPrimId.data(), nTris * 4, hipMemcpyHostToDevice);
+            if (te == hipSuccess) {
+                hipLaunchKernelGGL(triangle_boxes_kernel, dim3((unsigned)((nTris + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, dPrims, dSrcPos, (uint32_t)nTris, dLo4, dHi4);
+                te = hipGetLastError();
+            }
+        }
+        if (te != hipSuccess) {
+            rt::set_error("rt_scene_create: device allocation/upload of the primitives failed: %s", hipGetErrorString(te));
+            (void)hipFree(d_temp);
+            delete s;
+            return RT_ERR_HIP;
+        }
+    }
+    if (!getenv("RT_AMD_NO_QUERY_TREE"))
+        build_query_tree(flat, qt, getenv("RT_AMD_HOST_QUERY_BUILD") == nullptr, false, static_cast<const RefPrimitive*>(prims),
+                         reinterpret_cast<const float*>(dLo4), reinterpret_cast<const float*>(dHi4));
     const float queryMs = ms_since(tQuery);
     const auto tUpload = clock::now();
-    const size_t nPairs = flat.pairs.size(), nTris = flat.triPlane.size();
     const size_t nQNodes = qt.usable ? qt.nodes.size() : 0, nQPairs = qt.usable ? qt.pairs.size() : 0, nQTris = qt.usable ? nTris : 0;
     const size_t nQuadNodes = qt.usable ? qt.quadNodes.size() : 0, nQuadLeaves = qt.usable ? qt.quadLeaves.size() : 0;
     // (the last three: what the query-order copies are gathered from on the device - place -> triangle, and each triangle's
@@ -1874,7 +1929,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     // the small tables, as the kernels read them
     std::vector<uint32_t> hReflects(nTris / 32 + 1, 0u);
     for (size_t i = 0; i < nTris; i++) { // the material test of renderRay (src/recursive.cpp:62-80), once per triangle
-        const float* m = materials8 + 8 * (size_t)flat.triAttr[i].meshID;
+        const float* m = materials8 + 8 * (size_t)static_cast<const RefPrimitive*>(prims)[flat.srcPos[i]].meshID;
         if (m[3] != 0.0f || m[4] != 0.0f || m[5] != 0.0f) hReflects[i >> 5] |= 1u << (i & 31);
     }
     std::vector<GpuMaterial> hMat(nMaterials);
@@ -1921,9 +1976,14 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     const Box6* uLeafBox = nullptr;
     if (e == hipSuccess) {
         put(uPairs, flat.pairs.data(), nPairs);
-        put(uPlane, flat.triPlane.data(), nTris);
-        put(uEdges, flat.triEdges.data(), nTris);
-        put(uAttr, flat.triAttr.data(), nTris);
+        put(uPlane, deviceRecords ? nullptr : flat.triPlane.data(), nTris);
+        put(uEdges, deviceRecords ? nullptr : flat.triEdges.data(), nTris);
+        put(uAttr, deviceRecords ? nullptr : flat.triAttr.data(), nTris);
+        if (e == hipSuccess && deviceRecords && nTris) {
+            hipLaunchKernelGGL(triangle_records_kernel, dim3((unsigned)((nTris + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, dPrims, dSrcPos, dSrcPrimId,
+                               (uint32_t)nTris, const_cast<TriPlane*>(uPlane), const_cast<TriEdges*>(uEdges), const_cast<TriAttr*>(uAttr));
+            e = hipGetLastError();
+        }
         put(uBrute, flat.bruteOrder.data(), nTris);
         put(uLeafCounts, flat.leafCounts.data(), flat.leafCounts.size());
         put(uReflects, hReflects.data(), nTris / 32 + 1);
@@ -1950,6 +2010,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_textures), (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipMemset(s->d_textures, 0, (nMaterials ? nMaterials : 1) * sizeof(GpuTexture));
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // frames run on streams the null stream's work is not ordered with
+    (void)hipFree(d_temp);
     s->texturePixels.assign(nMaterials, nullptr);
     if (e != hipSuccess) {
         rt::set_error("rt_scene_create: device allocation/upload of %zu bytes failed: %s", total, hipGetErrorString(e));

@@ -155,6 +155,9 @@ struct FlatScene {
     std::vector<TriPlane> triPlane;
     std::vector<TriEdges> triEdges;
     std::vector<TriAttr> triAttr;
+    std::vector<uint32_t> srcPos;     // per compact triangle: its place in the caller's primitives() array ...
+    std::vector<uint32_t> srcPrimId;  // ... and the index it reports (TriAttr::primId); the three arrays above may be left empty
+                                      // (flatten's `records` = false: the caller computes them on the device from these)
     std::vector<uint32_t> bruteOrder;
     std::vector<uint32_t> leafCounts; // empty, or one entry per compact triangle: the size of the leaf that starts there, for leaves of 63 or more
     float rootLo[3], rootHi[3];
@@ -191,7 +194,10 @@ struct QueryTree {
 };
 // onDevice: try the device builder first (the host builder takes over if it cannot be used)
 // hostLayouts: also gather the triangle records and certificates into query-tree order on the host (the self-tests read them)
-void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice = false, bool hostLayouts = true);
+// prims: the caller's primitives() (needed when `flat` holds no triangle records); dLo4 / dHi4: the triangles' boxes already on the
+// current device (4 floats per compact triangle), for the device builder
+void build_query_tree(const FlatScene& flat, QueryTree& out, bool onDevice = false, bool hostLayouts = true, const RefPrimitive* prims = nullptr,
+                      const float* dLo4 = nullptr, const float* dHi4 = nullptr);
 
 // One node of a hierarchy built on the device: a child is a node index or a leaf reference (kLeafBit | count << 25 | first place in the
 // triangle order).
@@ -199,7 +205,7 @@ struct DeviceBuildNode {
     float lo[3], hi[3];
     uint32_t child[2];
 };
-bool device_build_query_hierarchy(const float* lo4, const float* hi4, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
+bool device_build_query_hierarchy(const float* lo4, const float* hi4, bool resident, uint32_t n, uint32_t leafMax, std::vector<DeviceBuildNode>& tree,
                                   std::vector<uint32_t>& order, uint32_t& depth, float* kernelMs);
 
 // One span of the reference's build as settled on the device (device_build_reference_spans): its box, its place in the primitive
@@ -216,7 +222,7 @@ bool device_build_reference_spans(const RefPrimitive* prims, uint32_t n, bool sa
 
 // Returns RT_OK or an error status with `err` describing it.
 int flatten(const RefNode* nodes, uint32_t nNodes, const RefPrimitive* prims, uint32_t nPrims, const uint32_t* primIds,
-            uint32_t nMaterials, FlatScene& out, const char** err);
+            uint32_t nMaterials, FlatScene& out, const char** err, bool records = true);
 
 } // namespace rt
 
