@@ -101,3 +101,45 @@ def test_five_primitives_and_fewer(rt):
     for n in (0, 1, 4, 5, 6, 9):
         _same(rt, base[:n], False)
         _same(rt, base[:n], True)
+
+
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+def test_every_triangle_stored_twice(rt, sah):
+    """Two copies of every triangle: equal sort keys in every span down to the leaves.  The SAH build's bin index is undefined
+    where a span holds nothing but equal keys; whatever the host build says (a tree or the refusal), the device build says too."""
+    base = _grid(16, True, 5)
+    prims = np.concatenate([base, base])
+    try:
+        host = rt.Bvh(prims, sah_binning=sah)
+    except RuntimeError as e:
+        with pytest.raises(RuntimeError) as again:
+            rt.Bvh(prims, sah_binning=sah, device=True)
+        assert str(again.value) == str(e)
+        return
+    dev = rt.Bvh(prims, sah_binning=sah, device=True)
+    assert np.array_equal(dev.nodes(), host.nodes()) and np.array_equal(dev.primitives(), host.primitives())
+    assert np.array_equal(dev.primitive_ids(), host.primitive_ids())
+    assert dev.device_info["host_primitives"] > 0
+
+
+@pytest.mark.parametrize("sah", [False, True], ids=["median", "sah"])
+def test_coordinates_that_are_not_numbers(rt, sah):
+    """A NaN and an infinity among the vertices: glm::min / glm::max skip a NaN operand, a NaN key has no place in a sort.  The
+    device hands the spans that hold them to the host builder; the arrays are the host's."""
+    prims = _grid(10, True, 6).view(np.float32).copy()
+    prims[7, 1] = np.nan
+    prims[11, 10] = np.inf
+    prims[40, 19] = -np.inf
+    try:
+        _same(rt, prims.view(np.uint32), sah)
+    except RuntimeError:
+        with pytest.raises(RuntimeError):
+            rt.Bvh(prims.view(np.uint32), sah_binning=sah)
+
+
+def test_a_quarter_of_a_million_triangles(rt):
+    """More levels than the first look at the open-span counters covers (SAH), and every level copy of the primitive order."""
+    prims = _grid(354, True, 7)  # 250,632 triangles
+    for sah in (False, True):
+        info = _same(rt, prims, sah)
+        assert info["host_primitives"] * 50 <= len(prims), info
