@@ -2541,7 +2541,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         RT_HIP(hipMalloc(&w.d_pathRays[1], pathRaysWanted * sizeof(RayRec)));
         w.pathRayCap = pathRaysWanted;
     }
-    const size_t countWords = 2 * kMaxRounds + kMaxTraceLaunches;
+    const size_t countWords = 3 * kMaxRounds + kMaxTraceLaunches; // active lists' fronts, rays per round, active lists' backs, trace launches
     if (!w.d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_roundCounts), countWords * sizeof(uint32_t)));
     // shadow rays: one per point light and numShadowSamples per area light for every shade task, generated and
     // traced in chunks of tasks that fit the shadow-ray buffer
@@ -2681,8 +2681,9 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     T.useBvh = features->enableAccelStructure ? 1u : 0u;
     T.waveTimes = nullptr;
     int roundNow = 0; // the path round being launched (0: another stage)
-    uint32_t nextFetch = 2 * kMaxRounds;
+    uint32_t nextFetch = 3 * kMaxRounds;
     uint32_t* const rayCounts = w.d_roundCounts + kMaxRounds;
+    uint32_t* const backCounts = w.d_roundCounts + 2 * kMaxRounds; // states at the back of each round's active list (path_logic_kernel)
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
     const uint32_t traceGrid = (uint32_t)scene->numCUs * scene->laneBlocksPerCU;
@@ -2867,6 +2868,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     };
 
     P.activeIn = nullptr, P.activeInCount = nullptr;
+    P.activeInCountBack = nullptr, P.activeOutCountBack = backCounts; // (the camera kernel fills the front only)
     P.activeOut = w.d_active[0], P.activeOutCount = w.d_roundCounts;
     P.activeRayIn = nullptr, P.activeRayOut = w.d_activeRay[0], P.rayCountOut = rayCounts;
     hipLaunchKernelGGL(camera_kernel, dim3(taskGrid < fullGrid ? taskGrid : fullGrid), dim3(kBlock), 0, st, P);
@@ -2985,6 +2987,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         P.pathRaysIn = static_cast<const RayRec*>(w.d_pathRays[(r - 1) & 1]), P.pathRays = static_cast<RayRec*>(w.d_pathRays[r & 1]);
         P.activeIn = w.d_active[(r - 1) & 1], P.activeInCount = w.d_roundCounts + (r - 1);
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
+        P.activeInCountBack = backCounts + (r - 1), P.activeOutCountBack = backCounts + r;
         P.activeRayIn = w.d_activeRay[(r - 1) & 1], P.activeRayOut = w.d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
         if (features->enableTransparency) hipLaunchKernelGGL(path_logic_kernel<true>, dim3(taskGrid), dim3(kBlock), 0, st, P);
         else hipLaunchKernelGGL(path_logic_kernel<false>, dim3(taskGrid), dim3(kBlock), 0, st, P);
@@ -3247,6 +3250,11 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     if (w.lastWasWavefront && w.lastRounds) { // a pixel still had rays to trace when the rounds ended
         uint32_t left = 0;
         RT_HIP(hipMemcpy(&left, w.d_roundCounts + w.lastRounds, sizeof(left), hipMemcpyDeviceToHost));
+        {
+            uint32_t back = 0; // the active list's other end
+            RT_HIP(hipMemcpy(&back, w.d_roundCounts + 2 * kMaxRounds + w.lastRounds, sizeof(back), hipMemcpyDeviceToHost));
+            left += back;
+        }
         if (left) {
             rt::set_error("%u pixels were unfinished after the frame's %u path rounds: the frame is incomplete; render with RT_RENDER_SERIAL",
                           left, w.lastRounds);

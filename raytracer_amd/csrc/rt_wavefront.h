@@ -95,6 +95,11 @@ struct WaveParams {
     uint32_t* activeOut;      // survivors
     const uint32_t* activeInCount;
     uint32_t* activeOutCount;
+    // The rounds' active lists are filled from both ends: states with a batch of candidate rays in flight from the front
+    // (counted by activeOutCount), states with one ray in flight from the back (entry stateCap - 1 - k, counted here), so
+    // that a wave of the next round's logic kernel holds states of one kind and runs one of the two long code paths.
+    const uint32_t* activeInCountBack; // null: the list has a front only (the camera kernel's)
+    uint32_t* activeOutCountBack;
     RayRec* pathRays;         // rays of the next round; activeRayOut[i] = first ray of state activeOut[i]
     const RayRec* pathRaysIn; // rays of the round whose hits this kernel consumes (a different buffer)
     uint32_t* rayCountOut;    // rays appended for the next round
@@ -1479,7 +1484,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
 {
     __shared__ uint32_t s_n[12], s_base[3];
     const int lane = threadIdx.x & 63;
-    const uint32_t total = *P.activeInCount;
+    const uint32_t front = *P.activeInCount, total = front + (P.activeInCountBack ? *P.activeInCountBack : 0u);
     uint32_t cPrimary = 0, cSecondary = 0, cDrop = 0;
     TraceCounters tc { 0, 0, 0 };
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) { // block-uniform trip count
@@ -1491,11 +1496,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         float* passes = nullptr;
         uint32_t slot = 0;
         if (i < total) {
-            slot = P.activeIn[i];
+            const uint32_t at = i < front ? i : P.stateCap - 1u - (i - front); // (total <= stateCap: the two ends do not meet)
+            slot = P.activeIn[at];
             load_header(P.states + (size_t)slot * P.stateStride, L);
             frames = P.frameBase + (size_t)slot * kFrameDwords;
             if (TRANSP) passes = P.passBase + (size_t)slot * kPassDwords;
-            L.rayBase = P.activeRayIn[i];
+            L.rayBase = P.activeRayIn[at];
             if (L.nRays > 1) {
                 L.state = PS_BATCH;
             } else {
@@ -1509,18 +1515,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) voi
         advance_lanes<TRANSP>(P, L, frames, passes, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
         const bool active = (L.state == PS_TRACE);
         const bool single = active && L.nRays <= 1; // a batch reserved its rays when it was emitted
-        uint32_t pos, rpos;
-        block_fetch2(P.activeOutCount, active, P.rayCountOut, single, lane, s_n, s_base, pos, rpos);
+        uint32_t posFront, posBack, rpos;
+        reserve_slots3(P.activeOutCount, 0xffffffffu, (active && !single) ? 1u : 0u, P.activeOutCountBack, 0xffffffffu, single ? 1u : 0u, P.rayCountOut,
+                       0xffffffffu, single ? 1u : 0u, lane, s_n, s_base, posFront, posBack, rpos);
         if (single) {
             L.nRays = 1;
             L.rayBase = rpos;
             if (rpos < P.rayCap) store_ray(P.pathRays + rpos, L.to, L.td, FLT_MAX, 0u);
             else cDrop++;
         }
-        if (active) {
+        if (active) { // (every state is on at most one list: front + back <= stateCap)
+            const uint32_t at = single ? P.stateCap - 1u - posBack : posFront;
             store_header(P.states + (size_t)slot * P.stateStride, L);
-            P.activeOut[pos] = slot;
-            P.activeRayOut[pos] = L.rayBase;
+            P.activeOut[at] = slot;
+            P.activeRayOut[at] = L.rayBase;
         }
     }
     flush_counters(P.stats, lane, cPrimary, 0, cSecondary, tc, 0, cDrop);
