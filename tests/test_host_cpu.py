@@ -290,3 +290,19 @@ def test_flatten_rejects_malformed_trees(rt):
         assert rc == rt.RT_ERR_INVALID and "twice" in msg
     rc, msg = create(nodes, nm=0)  # primitives refer to mesh 0 but no material is given
     assert rc == rt.RT_ERR_INVALID and "material" in msg
+
+
+def test_device_tree_build_without_a_gpu_says_so(rt):
+    """rt_bvh_build_device never falls back to the host build by itself: without a usable GPU it returns RT_ERR_HIP and names
+    rt_bvh_build; spans of at most four primitives need no device (the root is a leaf)."""
+    lib = rt.lib()
+    count = C.c_int(0)
+    if lib.rt_device_count(C.byref(count)) == rt.RT_OK and count.value > 0:
+        pytest.skip("a GPU is present: tests/test_device_tree_build.py covers the device build")
+    prims, _, _, _ = O.load_scene_arrays("cornell")
+    with pytest.raises(rt.RtError) as e:
+        rt.Bvh(prims, device=True)
+    assert e.value.code == rt.RT_ERR_HIP and "rt_bvh_build" in str(e.value)
+    small = rt.Bvh(prims[:3], device=True)
+    host = rt.Bvh(prims[:3])
+    assert np.array_equal(small.nodes(), host.nodes()) and np.array_equal(small.primitives(), host.primitives())
