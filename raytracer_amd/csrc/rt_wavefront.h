@@ -537,18 +537,24 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
             if (exhausted && chunkNext == chunkEnd) break;
             continue;
         }
+        // A lane whose query has ended stays idle until the wave next looks for new rays (the top of this loop), so what remains
+        // to be done for it - the proof that its result is the reference's, its record - waits until then as well and runs once
+        // for all the lanes that ended in these steps, instead of after every step for the two or three that ended in it.
+        bool settle = false;
 #pragma unroll 1
         for (int it = 0; it < kStepsPerCheck; it++) {
             const bool ended = trace_wave_step<CULL, COUNT, STACK, QUERY, ANY>(S, has, T, stack, tc);
+            if (ended) has = false, settle = true;
+        }
+        if (__ballot(settle) != 0ull) {
             bool unproven = false;
-            if (ended) {
+            if (settle) {
                 if (QUERY) {
                     unproven = !query_result_proven(S, T.R, T.t, T.tri, ANY ? -1.0f : T.tieT, T.lost);
                     for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
                         if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
                 }
                 if (!unproven) P.hits[idx] = HitRec { T.t, T.tri };
-                has = false;
             }
             if (QUERY && __ballot(unproven) != 0ull) {
                 const uint32_t pos = wave_fetch(P.fallCount, unproven, lane);
