@@ -1913,6 +1913,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_GROUP
             }
             if (__ballot(has && (T.lq >= G || (T.nq == 0 && T.lq > 0))) != 0ull)
                 group_leaf_step<COUNT, G, QUERY, ANY>(S, T, q, j, has && T.lq > 0, tc);
+        }
+        // (groups whose walk has ended are settled together here, once per four steps: a group idles until the wave next looks for
+        // new rays anyway, and the settling code runs for however few groups need it at the cost of the whole wave)
+        {
             const bool done = has && T.nq == 0 && T.lq == 0;
             if (__ballot(done) != 0ull) {
                 bool proven = true;
