@@ -495,10 +495,19 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
     TraceLane T;
     trace_lane_clear(T);
     if ((blockIdx.x * kBlock + (threadIdx.x & ~63u)) >= total) return; // nothing for this wave, now or later
+    // A lane whose query has ended stays idle until the wave next looks for new rays (the top of the loop), so what remains
+    // to be done for it - the proof that its result is the reference's, its record - waits until then as well and runs once
+    // for all the lanes that ended in these steps, instead of after every step for the two or three that ended in it; and it
+    // runs between the fetch of the lanes' next rays and their set-up, so that the wave waits for those fetches once.
+    bool settle = false;
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         // new rays are started for several idle lanes at a time: the set-up of a ray is long and runs with only those lanes
-        if (idle != 0ull && (first || !exhausted || chunkNext < chunkEnd) && (first || __popcll(idle) >= kRefillLanes)) {
+        const bool refill = idle != 0ull && (first || !exhausted || chunkNext < chunkEnd) && (first || __popcll(idle) >= kRefillLanes);
+        uint32_t idxNew = 0xffffffffu;
+        bool fetched = false;
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+        if (refill) {
             uint32_t next = 0xffffffffu;
             if (first) {
                 next = blockIdx.x * kBlock + threadIdx.x;
@@ -516,12 +525,34 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
                 chunkNext += min(n, avail);
             }
             first = false;
+            if (!has) idxNew = next;
+            if (!has && idxNew < total) {
+                if (P.indirect && total >= P.indirectFrom) idxNew = P.indirect[idxNew]; // from here on the ray's own index
+                const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idxNew * P.rayStride);
+                a = q[0], b = q[1];
+                fetched = true;
+            }
+        }
+        if (__ballot(settle) != 0ull) { // (idx and T are still those of the query that ended)
+            bool unproven = false;
+            if (settle) {
+                if (QUERY) {
+                    unproven = !query_result_proven(S, T.R, T.t, T.tri, ANY ? -1.0f : T.tieT, T.lost);
+                    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
+                        if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
+                }
+                if (!unproven) P.hits[idx] = HitRec { T.t, T.tri };
+            }
+            if (QUERY && __ballot(unproven) != 0ull) {
+                const uint32_t pos = wave_fetch(P.fallCount, unproven, lane);
+                if (unproven) P.fallList[pos] = idx;
+            }
+            settle = false;
+        }
+        if (refill) {
             bool unfit = false;
-            if (!has) idx = next;
-            if (!has && idx < total) {
-                if (P.indirect && total >= P.indirectFrom) idx = P.indirect[idx]; // from here on the ray's own index
-                const float4* q = reinterpret_cast<const float4*>(P.rays + (size_t)idx * P.rayStride);
-                const float4 a = q[0], b = q[1];
+            if (!has) idx = idxNew;
+            if (fetched) {
                 has = trace_begin<COUNT>(S, P.useBvh != 0, T, make3(a.x, a.y, a.z), make3(b.x, b.y, b.z), a.w, tc);
                 steps = 0;
                 if (!has) P.hits[idx] = HitRec { T.t, T.tri };
@@ -537,29 +568,10 @@ __global__ __launch_bounds__(kBlock) RT_TRACE_WAVES void trace_kernel(const Trac
             if (exhausted && chunkNext == chunkEnd) break;
             continue;
         }
-        // A lane whose query has ended stays idle until the wave next looks for new rays (the top of this loop), so what remains
-        // to be done for it - the proof that its result is the reference's, its record - waits until then as well and runs once
-        // for all the lanes that ended in these steps, instead of after every step for the two or three that ended in it.
-        bool settle = false;
 #pragma unroll 1
         for (int it = 0; it < kStepsPerCheck; it++) {
             const bool ended = trace_wave_step<CULL, COUNT, STACK, QUERY, ANY>(S, has, T, stack, tc);
             if (ended) has = false, settle = true;
-        }
-        if (__ballot(settle) != 0ull) {
-            bool unproven = false;
-            if (settle) {
-                if (QUERY) {
-                    unproven = !query_result_proven(S, T.R, T.t, T.tri, ANY ? -1.0f : T.tieT, T.lost);
-                    for (uint32_t s = 0; s < S.nSpheres; s++) // src/bvh.cpp:366-367
-                        if (sphere_test(S.spheres[s], T.R.o, T.R.d, T.t)) T.tri = kSphereBase + s;
-                }
-                if (!unproven) P.hits[idx] = HitRec { T.t, T.tri };
-            }
-            if (QUERY && __ballot(unproven) != 0ull) {
-                const uint32_t pos = wave_fetch(P.fallCount, unproven, lane);
-                if (unproven) P.fallList[pos] = idx;
-            }
         }
         if (budget != 0) { // the few long rays would hold the whole stage at one-lane speed: hand them over
             steps += kStepsPerCheck;
