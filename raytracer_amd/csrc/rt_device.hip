@@ -195,6 +195,10 @@ constexpr uint32_t kNoHit = 0xffffffffu;
 constexpr uint32_t kSphereBase = 0xf0000000u; // tri >= kSphereBase: sphere index = tri - kSphereBase
 constexpr uint32_t kTraversalDone = 0xffffffffu;
 constexpr uint64_t kMaxQueueTasks = 1ull << 29; // per queue
+#ifndef RT_QSTACK
+#define RT_QSTACK 16
+#endif
+constexpr int kQueryStack = RT_QSTACK; // per-lane stack entries of the one-ray-per-lane launches in the query tree (an entry that finds no room sends its ray to the caller's tree)
 constexpr uint32_t kMaxRounds = 4096;            // sequential rays per pixel the round-based path stage accepts
 constexpr uint32_t kTraceSlotsPerRound = 8; // counters one stage's launches take at most: hand-over list, fall-back list, up to six launches (second pass included)
 constexpr uint32_t kMaxTraceLaunches = kTraceSlotsPerRound * kMaxRounds + 1024; // work counters for the trace launches of one frame
@@ -2712,13 +2716,13 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
                     if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, true, 8, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
                     else if (groupLanes == 16)
                         hipLaunchKernelGGL((group_trace_kernel<true, true, 16, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
-                    else hipLaunchKernelGGL((trace_kernel<true, true, 16, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+                    else hipLaunchKernelGGL((trace_kernel<true, true, kQueryStack, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
                     return;
                 }
                 if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
                 else if (groupLanes == 16)
                     hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
-                else hipLaunchKernelGGL((trace_kernel<true, false, 16, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+                else hipLaunchKernelGGL((trace_kernel<true, false, kQueryStack, true, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
                 return;
             }
             if (groupLanes >= 8 && scene->quadTrace && scene->queryView.quadNodes && !count) { // four lanes per ray instead
@@ -2729,13 +2733,13 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
                 if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, true, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
                 else if (groupLanes == 16)
                     hipLaunchKernelGGL((group_trace_kernel<true, true, 16, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
-                else hipLaunchKernelGGL((trace_kernel<true, true, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+                else hipLaunchKernelGGL((trace_kernel<true, true, kQueryStack, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
                 return;
             }
             if (groupLanes == 8) hipLaunchKernelGGL((group_trace_kernel<true, false, 8, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
             else if (groupLanes == 16)
                 hipLaunchKernelGGL((group_trace_kernel<true, false, 16, true>), dim3(gridNow), dim3(kBlock), 0, st, T, qreserve);
-            else hipLaunchKernelGGL((trace_kernel<true, false, 16, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
+            else hipLaunchKernelGGL((trace_kernel<true, false, kQueryStack, true>), dim3(traceGrid), dim3(kBlock), 0, st, T);
             return;
         }
 #define RT_TRACE_CASE(CULL, COUNT)                                                                                        \
