@@ -134,6 +134,10 @@ struct rt_scene {
     uint64_t useCounter = 0;
     int numCUs = 256;
     uint32_t laneBlocksPerCU = 8; // grid of the one-ray-per-lane trace kernel (RT_AMD_TRACE_BLOCKS overrides)
+    // ... of a launch sequence of several frames, or of frames that share the GPU with others: as many workgroups as a CU holds at
+    // a time (four: 34 KB of LDS each), so that a lane walks several rays in turn and the wave's lanes are refilled, instead of one
+    // ray per lane and a second generation of workgroups that each wait for their slowest ray (RT_AMD_TRACE_BLOCKS_POOLED overrides)
+    uint32_t laneBlocksPerCUPooled = 4;
     uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
@@ -2093,7 +2097,8 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
         const int g = atoi(e);
         if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) s->groupLanes = (uint32_t)g;
     }
-    if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
+    if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = s->laneBlocksPerCUPooled = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
+    if (const char* e = getenv("RT_AMD_TRACE_BLOCKS_POOLED")) s->laneBlocksPerCUPooled = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     if (const char* e = getenv("RT_AMD_GROUP_BLOCKS")) s->groupBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 0);
     if (const char* e = getenv("RT_AMD_PATH_MODE")) s->pathMode = atoi(e);
     if (const char* e = getenv("RT_AMD_PATH_QUADS")) s->pathQuads = atoi(e);
@@ -2690,7 +2695,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     uint32_t* const backCounts = w.d_roundCounts + 2 * kMaxRounds; // states at the back of each round's active list (path_logic_kernel)
     const int stackClass = scene->treeDepth <= 16 ? 0 : (scene->treeDepth <= 24 ? 1 : 2);
     // LDS per workgroup = stack entries * 1 KiB: the grid keeps every CU's share of waves resident
-    const uint32_t traceGrid = (uint32_t)scene->numCUs * scene->laneBlocksPerCU;
+    const uint32_t traceGrid = (uint32_t)scene->numCUs * ((overlapped || nFrames > 1) ? scene->laneBlocksPerCUPooled : scene->laneBlocksPerCU);
     // every ray of a group launch (at most laneModeAbove of them) gets its group from the grid position
     const uint32_t groupRaysPerBlock = kBlock / (scene->groupLanes > 1 ? scene->groupLanes : 8u);
     const uint32_t groupGrid = scene->groupBlocksPerCU ? (uint32_t)scene->numCUs * scene->groupBlocksPerCU
