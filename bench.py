@@ -190,7 +190,9 @@ def main():
     # One rank of several renders a share of every frame: its stages are small, and fewer, longer sequences serve it better
     # (one rank of eight, 20 steps: 0.73 ms per frame with 2 sequences of 10 in flight, 0.81 ms with 4 of 5).
     whole = world == 1 or by_frames  # this rank renders whole frames
-    F = max(1, min(8, args.frames_in_flight or (4 if whole else 2)))
+    # (a short job fills three streams with longer sequences better than four with short ones: 20 steps as 7 + 7 + 6 take 3.58 ms per
+    # step, as 4 x 5 3.69 - sequences of five pool too few rays per stage)
+    F = max(1, min(8, args.frames_in_flight or ((4 if my_steps >= 32 else 3) if whole else 2)))
     K = max(1, min(api.RT_MAX_FRAMES, args.frames_per_sequence or (8 if whole else 16), -(-max(my_steps, 1) // F)))  # frames per launch sequence
     if args.sequence_sizes:
         K = max(1, min(api.RT_MAX_FRAMES, max(int(x) for x in args.sequence_sizes.split(","))))
