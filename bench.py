@@ -384,8 +384,9 @@ def main():
     free_b, total_b = torch.cuda.mem_get_info(dev)
     device_mem_gb = (total_b - free_b) / 1e9
 
-    # one frame with nothing else queued: its latency, and the duration of the rt_render launch sequence by itself
-    # (events on the stream the launches run on)
+    # one frame with nothing else queued: its latency - from the call to the frame in host memory and rt_sync's word that it is
+    # complete (which also hands the frame's round sizes to the next frame's launch plan, as for any caller that renders
+    # frame after frame) - and the duration of the rt_render launch sequence by itself (events on the stream the launches run on)
     alone, kernel_ms = [], []
     for i in range(6):
         ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
@@ -393,6 +394,10 @@ def main():
         t1 = time.perf_counter()
         run(0, i, 1, ev, flags)
         torch.cuda.synchronize()
+        try:
+            scene.sync(streams[0].cuda_stream)
+        except api.RtError as e:
+            fail(f"the frame rendered alone is incomplete: {e}")
         alone.append((time.perf_counter() - t1) * 1e3)
         kernel_ms.append(ev[0].elapsed_time(ev[1]))
     alone_ms, kernel_ms = float(np.median(alone[1:])), float(np.median(kernel_ms[1:]))

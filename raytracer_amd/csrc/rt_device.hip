@@ -75,6 +75,11 @@ struct Workspace {
     unsigned long long* d_waveTimes = nullptr; // RT_AMD_WAVE_TIMES: start / end clock of every wave of one round's group launch
     uint32_t waveTimesWaves = 0;
     uint64_t lastCfg = 0;  // ... and the description its queue sizes are remembered under (rt_scene::seenQueues)
+    // What rt_sync reads of a frame - the counters, the queue counters, the rounds' counters - is copied to pinned host memory
+    // by the frame's own launch sequence: rt_sync then waits for the stream once instead of once per blocking copy.
+    unsigned char* h_status = nullptr;
+    bool statusQueued = false;     // the last sequence queued here ends with those copies
+    uint32_t statusCountWords = 0; // d_roundCounts words among them
 };
 
 struct RetiredFrame {
@@ -217,6 +222,25 @@ enum CarrySlot { S_QMAX_SHADE = 10, S_QMAX_LEAF = 11, S_FALL_SUM = 12 };
 // The counters exist kStatCopies times, 256 B apart; a workgroup adds to the copy of its index and rt_sync sums them.
 // (Additions to one address are served one at a time, about 9 ns each: 8,000 waves ending together would wait 70 us.)
 constexpr uint32_t kStatCopies = 64, kStatStride = 32; // stride in counters
+constexpr size_t kCountWords = 3 * kMaxRounds + kMaxTraceLaunches; // Workspace::d_roundCounts: active lists' fronts, rays per round, active lists' backs, trace launches
+constexpr size_t kStatusStatsBytes = kStatCopies * kStatStride * sizeof(unsigned long long), kStatusWorkBytes = 256; // Workspace::h_status: d_stats, d_work, d_roundCounts
+
+// Ends a frame's launch sequence with the copies of what rt_sync reads (Workspace::h_status).  Best effort: without them
+// rt_sync copies as it reads.
+static void queue_status(Workspace& w, hipStream_t st, const uint32_t countWords)
+{
+    w.statusQueued = false;
+    if (!w.h_status && hipHostMalloc(reinterpret_cast<void**>(&w.h_status), kStatusStatsBytes + kStatusWorkBytes + kCountWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        w.h_status = nullptr;
+        (void)hipGetLastError();
+        return;
+    }
+    bool ok = hipMemcpyAsync(w.h_status, w.d_stats, kStatusStatsBytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(w.h_status + kStatusStatsBytes, w.d_work, kStatusWorkBytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (countWords)
+        ok = ok && hipMemcpyAsync(w.h_status + kStatusStatsBytes + kStatusWorkBytes, w.d_roundCounts, countWords * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+    w.statusQueued = ok, w.statusCountWords = countWords;
+}
 
 struct RenderParams {
     SceneView S;
@@ -1759,6 +1783,7 @@ void free_workspace(Workspace* w)
 {
     if (!w) return;
     (void)hipFree(w->d_stats), (void)hipFree(w->d_work), (void)hipFree(w->d_cams), (void)hipFree(w->d_accum), (void)hipFree(w->d_nonfinite);
+    if (w->h_status) (void)hipHostFree(w->h_status);
     (void)hipFree(w->d_shadeQ), (void)hipFree(w->d_leafQ), (void)hipFree(w->d_states), (void)hipFree(w->d_frames), (void)hipFree(w->d_passes);
     (void)hipFree(w->d_active[0]), (void)hipFree(w->d_active[1]), (void)hipFree(w->d_activeRay[0]), (void)hipFree(w->d_activeRay[1]);
     (void)hipFree(w->d_roundCounts), (void)hipFree(w->d_pathRays[0]), (void)hipFree(w->d_pathRays[1]);
@@ -2366,6 +2391,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
     RT_HIP(hipMemsetAsync(w.d_work, 0, 256, st));
     w.lastWasWavefront = false;
+    w.statusQueued = false;
     if (nWork == 0) return RT_OK;
     // countRef: the counters of the reference's walk (its rays, the caller's tree); countSchedule: the same counters, and
     // the query tree's, for the frame exactly as it is scheduled by default (query tree, candidate batches, handed-over rays)
@@ -2419,6 +2445,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         else if (!cull && !count) hipLaunchKernelGGL((render_kernel<false, false, true>), dim3(grid), dim3(kBlock), 0, st, P);
         else hipLaunchKernelGGL((render_kernel<false, true, true>), dim3(grid), dim3(kBlock), 0, st, P);
         RT_HIP(hipGetLastError());
+        queue_status(w, st, 0);
         return RT_OK;
     }
 
@@ -2550,7 +2577,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         RT_HIP(hipMalloc(&w.d_pathRays[1], pathRaysWanted * sizeof(RayRec)));
         w.pathRayCap = pathRaysWanted;
     }
-    const size_t countWords = 3 * kMaxRounds + kMaxTraceLaunches; // active lists' fronts, rays per round, active lists' backs, trace launches
+    const size_t countWords = kCountWords;
     if (!w.d_roundCounts) RT_HIP(hipMalloc(reinterpret_cast<void**>(&w.d_roundCounts), countWords * sizeof(uint32_t)));
     // shadow rays: one per point light and numShadowSamples per area light for every shade task, generated and
     // traced in chunks of tasks that fit the shadow-ray buffer
@@ -3038,6 +3065,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     hipLaunchKernelGGL(resolve_kernel, dim3(resolveGrid), dim3(kBlock), 0, st, P);
     RT_HIP(hipGetLastError());
     w.lastWasWavefront = true;
+    queue_status(w, st, nextFetch);
     return RT_OK;
 }
 
@@ -3139,9 +3167,19 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     (void)scene;
     unsigned long long h[S_COUNT] = {};
     unsigned long long carried[3] = {}; // S_QMAX_SHADE, S_QMAX_LEAF, S_FALL_SUM: earlier frames of a sequence rendered frame by frame
+    // (the stream has been waited for: the copies the sequence ended with are complete)
+    const bool copied = w.statusQueued && w.h_status != nullptr;
+    auto read_counts = [&](const uint32_t lo, const size_t n, uint32_t* dst) -> hipError_t {
+        if (copied && lo + n <= w.statusCountWords) {
+            memcpy(dst, w.h_status + kStatusStatsBytes + kStatusWorkBytes + (size_t)lo * sizeof(uint32_t), n * sizeof(uint32_t));
+            return hipSuccess;
+        }
+        return hipMemcpy(dst, w.d_roundCounts + lo, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    };
     {
         unsigned long long all[kStatCopies * kStatStride];
-        RT_HIP(hipMemcpy(all, w.d_stats, sizeof(all), hipMemcpyDeviceToHost));
+        if (copied) memcpy(all, w.h_status, sizeof(all));
+        else RT_HIP(hipMemcpy(all, w.d_stats, sizeof(all), hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < kStatCopies; c++)
             for (int i = 0; i < S_COUNT; i++) h[i] += all[c * kStatStride + i];
         for (int i = 0; i < 3; i++) carried[i] = all[S_COUNT + i];
@@ -3190,7 +3228,7 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
         if (w.lastWasWavefront && !w.fallSlots.empty()) {
             const uint32_t lo = w.fallSlots.front(), hi = w.fallSlots.back();
             std::vector<uint32_t> c(hi - lo + 1);
-            RT_HIP(hipMemcpy(c.data(), w.d_roundCounts + lo, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            RT_HIP(read_counts(lo, c.size(), c.data()));
             for (uint32_t slot : w.fallSlots) stats->referenceTreeQueries += c[slot - lo];
         }
         stats->referenceTreeQueries += carried[S_FALL_SUM - S_COUNT]; // earlier frames of a sequence rendered frame by frame
@@ -3201,7 +3239,8 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     }
     if (w.lastWasWavefront) { // did every deferred task fit its queue?  The counters keep counting past the capacity.
         uint32_t q[2];
-        RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
+        if (copied) memcpy(q, w.h_status + kStatusStatsBytes + 8 * sizeof(uint32_t), sizeof(q));
+        else RT_HIP(hipMemcpy(q, w.d_work + 8, sizeof(q), hipMemcpyDeviceToHost));
         // (a sequence rendered frame by frame: the fullest queues any of its frames had)
         q[0] = (uint32_t)std::max<unsigned long long>(q[0], carried[S_QMAX_SHADE - S_COUNT]);
         q[1] = (uint32_t)std::max<unsigned long long>(q[1], carried[S_QMAX_LEAF - S_COUNT]);
@@ -3231,8 +3270,8 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     if (w.lastWasWavefront && w.lastRounds) {
         const uint32_t n = w.lastRounds;
         roundRays.assign(n, 0u);
-        RT_HIP(hipMemcpy(&roundRays[0], w.d_roundCounts, sizeof(uint32_t), hipMemcpyDeviceToHost)); // round 1: the camera's rays
-        if (n > 1) RT_HIP(hipMemcpy(&roundRays[1], w.d_roundCounts + kMaxRounds + 1, (n - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        RT_HIP(read_counts(0, 1, &roundRays[0])); // round 1: the camera's rays
+        if (n > 1) RT_HIP(read_counts(kMaxRounds + 1, n - 1, &roundRays[1]));
         uint32_t most = 0;
         for (uint32_t v : roundRays) most = std::max(most, v);
         if (w.lastWork) {
@@ -3258,10 +3297,10 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
     }
     if (w.lastWasWavefront && w.lastRounds) { // a pixel still had rays to trace when the rounds ended
         uint32_t left = 0;
-        RT_HIP(hipMemcpy(&left, w.d_roundCounts + w.lastRounds, sizeof(left), hipMemcpyDeviceToHost));
+        RT_HIP(read_counts(w.lastRounds, 1, &left));
         {
             uint32_t back = 0; // the active list's other end
-            RT_HIP(hipMemcpy(&back, w.d_roundCounts + 2 * kMaxRounds + w.lastRounds, sizeof(back), hipMemcpyDeviceToHost));
+            RT_HIP(read_counts(2 * kMaxRounds + w.lastRounds, 1, &back));
             left += back;
         }
         if (left) {

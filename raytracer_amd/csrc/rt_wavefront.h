@@ -1497,8 +1497,11 @@ __global__ __launch_bounds__(kBlock) void camera_kernel(const WaveParams P)
 }
 
 // Round r >= 1, after trace_kernel: consume the hit of every active state's ray, advance its recursion.
+#ifndef RT_LOGIC_WAVES
+#define RT_LOGIC_WAVES 2 // waves per SIMD the path logic is compiled for (3: 168 registers, 444 B per lane spilled, a pooled frame 7 % slower)
+#endif
 template <bool TRANSP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2))) void path_logic_kernel(const WaveParams P)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_LOGIC_WAVES))) void path_logic_kernel(const WaveParams P)
 {
     __shared__ uint32_t s_n[12], s_base[3];
     const int lane = threadIdx.x & 63;

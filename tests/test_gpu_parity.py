@@ -521,6 +521,39 @@ def test_frames_on_several_streams_overlap_without_mixing():
     assert len({w["stats"].rays for w in want}) > 1  # the frames do differ
 
 
+def test_sync_reports_the_last_frame_queued_on_a_stream():
+    """rt_sync reads what the frame's own launch sequence copied to host memory behind its kernels.  Two frames queued on one
+    stream without a sync in between - a glossy one, then a smaller mirror one, then the depth-first kernel - report the ray
+    counts of the frame queued last, every time, and the frames are those of renders done one at a time."""
+    torch = pytest.importorskip("torch")
+    g, _, _ = scene_pair("knot")
+    big, _ = both_features(enableGlossyReflection=1, numGlossySamples=3)
+    small, _ = both_features()
+    cam_big, cam_small = both_cameras(320, 184, dist=2.2)[0], both_cameras(160, 96, dist=3.0)[0]
+    want_big = g.render_image(cam_big, big, 320, 184, start_depth=2, want_ids=False)
+    want_small = g.render_image(cam_small, small, 160, 96, start_depth=3, want_ids=False)
+    want_serial = g.render_image(cam_small, small, 160, 96, start_depth=3, want_ids=False, flags=api.RT_RENDER_SERIAL)
+    assert want_big["stats"].rays != want_small["stats"].rays
+    a = torch.full((184, 320, 3), -1.0, dtype=torch.float32, device="cuda")
+    b = torch.full((96, 160, 3), -1.0, dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    for rep in range(2):
+        g.render_device(cam_big, big, 320, 184, 2, a.data_ptr(), stream=st.cuda_stream)
+        g.render_device(cam_small, small, 160, 96, 3, b.data_ptr(), stream=st.cuda_stream)
+        stats = g.sync(st.cuda_stream)
+        assert stats.rays == want_small["stats"].rays and stats.pipeline == want_small["stats"].pipeline
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), want_big["rgb"].view(np.uint32))
+        assert np.array_equal(b.cpu().numpy().view(np.uint32), want_small["rgb"].view(np.uint32))
+        assert g.sync(st.cuda_stream).rays == stats.rays  # asked again: the same answer
+        g.render_device(cam_small, small, 160, 96, 3, b.data_ptr(), stream=st.cuda_stream)
+        g.render_device(cam_big, big, 320, 184, 2, a.data_ptr(), stream=st.cuda_stream)
+        assert g.sync(st.cuda_stream).rays == want_big["stats"].rays
+        g.render_device(cam_small, small, 160, 96, 3, b.data_ptr(), flags=api.RT_RENDER_SERIAL, stream=st.cuda_stream)
+        stats = g.sync(st.cuda_stream)
+        assert stats.rays == want_serial["stats"].rays and stats.pipeline == api.RT_PIPELINE_DEPTH_FIRST
+        assert np.array_equal(b.cpu().numpy().view(np.uint32), want_serial["rgb"].view(np.uint32))
+
+
 def test_frames_rendered_together_equal_frames_rendered_alone():
     """rt_render_frames (the reference's loop over cameras, src/main.cpp:515-526, as one launch sequence whose stages trace the
     rays of every frame together) writes, for each camera, the frame, primary ids and distances of rt_render bit for bit, and
