@@ -143,6 +143,7 @@ struct rt_scene {
     // a time (four: 34 KB of LDS each), so that a lane walks several rays in turn and the wave's lanes are refilled, instead of one
     // ray per lane and a second generation of workgroups that each wait for their slowest ray (RT_AMD_TRACE_BLOCKS_POOLED overrides)
     uint32_t laneBlocksPerCUPooled = 4;
+    uint32_t logicBlocksPerCU = 8; // workgroups per CU of a path_logic_kernel launch (RT_AMD_LOGIC_BLOCKS; a CU holds two at a time, which fill its registers)
     uint32_t groupBlocksPerCU = 0; // grid of the group trace kernel; 0 = one group per possible ray (RT_AMD_GROUP_BLOCKS overrides)
     uint32_t groupLanes = 8; // lanes sharing one ray in the path rounds (RT_AMD_GROUP_LANES overrides; 1 = one ray per lane)
     uint32_t batchWindow = 5;       // children of a last-level glossy loop traced per round as candidates (RT_AMD_BATCH_WINDOW; below 2 and
@@ -227,9 +228,10 @@ constexpr size_t kStatusStatsBytes = kStatCopies * kStatStride * sizeof(unsigned
 
 // Ends a frame's launch sequence with the copies of what rt_sync reads (Workspace::h_status).  Best effort: without them
 // rt_sync copies as it reads.
-static void queue_status(Workspace& w, hipStream_t st, const uint32_t countWords)
+static void queue_status(Workspace& w, hipStream_t st, uint32_t countWords)
 {
     w.statusQueued = false;
+    if (countWords > kCountWords) countWords = (uint32_t)kCountWords;
     if (!w.h_status && hipHostMalloc(reinterpret_cast<void**>(&w.h_status), kStatusStatsBytes + kStatusWorkBytes + kCountWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         w.h_status = nullptr;
         (void)hipGetLastError();
@@ -2124,6 +2126,7 @@ int rt_scene_create(const void* nodes, uint32_t nNodes, const void* prims, uint3
     }
     if (const char* e = getenv("RT_AMD_TRACE_BLOCKS")) s->laneBlocksPerCU = s->laneBlocksPerCUPooled = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     if (const char* e = getenv("RT_AMD_TRACE_BLOCKS_POOLED")) s->laneBlocksPerCUPooled = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
+    if (const char* e = getenv("RT_AMD_LOGIC_BLOCKS")) s->logicBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 1);
     if (const char* e = getenv("RT_AMD_GROUP_BLOCKS")) s->groupBlocksPerCU = (uint32_t)(atoi(e) > 0 ? atoi(e) : 0);
     if (const char* e = getenv("RT_AMD_PATH_MODE")) s->pathMode = atoi(e);
     if (const char* e = getenv("RT_AMD_PATH_QUADS")) s->pathQuads = atoi(e);
@@ -3025,8 +3028,9 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
         P.activeOut = w.d_active[r & 1], P.activeOutCount = w.d_roundCounts + r;
         P.activeInCountBack = backCounts + (r - 1), P.activeOutCountBack = backCounts + r;
         P.activeRayIn = w.d_activeRay[(r - 1) & 1], P.activeRayOut = w.d_activeRay[r & 1], P.rayCountOut = rayCounts + r;
-        if (features->enableTransparency) hipLaunchKernelGGL(path_logic_kernel<true>, dim3(taskGrid), dim3(kBlock), 0, st, P);
-        else hipLaunchKernelGGL(path_logic_kernel<false>, dim3(taskGrid), dim3(kBlock), 0, st, P);
+        const uint32_t logicGrid = (uint32_t)scene->numCUs * scene->logicBlocksPerCU;
+        if (features->enableTransparency) hipLaunchKernelGGL(path_logic_kernel<true>, dim3(logicGrid), dim3(kBlock), 0, st, P);
+        else hipLaunchKernelGGL(path_logic_kernel<false>, dim3(logicGrid), dim3(kBlock), 0, st, P);
     }
     // what the batched loops left for later: their children's hit records and the grandchildren's rays
     if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
