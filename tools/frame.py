@@ -27,6 +27,8 @@ if pooled > 1:
         k = i % inflight
         scene.render_frames_device([cam] * min(pooled, n - first), feat, W, H, wl["start_depth"], bufs[k].data_ptr(), flags=flags,
                                    stream=streams[k].cuda_stream)
+        if inflight == 1:  # one sequence at a time: its status read before the next (which gives the next its launch plan)
+            scene.sync(streams[k].cuda_stream)
     stream = streams[0].cuda_stream
 elif inflight > 1:
     streams = [torch.cuda.Stream() for _ in range(inflight)]
@@ -35,7 +37,8 @@ elif inflight > 1:
         scene.render_device(cam, feat, W, H, wl["start_depth"], frames[k % inflight].data_ptr(), flags=flags, stream=streams[k % inflight].cuda_stream)
     stream = streams[0].cuda_stream
 else:
-    for _ in range(n):
+    for _ in range(n):  # frame after frame, each one's status read before the next (which gives the next its launch plan)
         scene.render_device(cam, feat, W, H, wl["start_depth"], frame.data_ptr(), flags=flags, stream=stream)
+        scene.sync(stream)
 torch.cuda.synchronize()
 print("stats", scene.sync(stream).rays if hasattr(scene.sync(stream), "rays") else "ok")
