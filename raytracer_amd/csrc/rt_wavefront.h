@@ -1236,10 +1236,13 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             }
         }
         // ---- queue slots for everything this pass produced (a lane asks for one kind): one trip to the counters ----
+        // The two task queues are reserved without regard to their ends, and every slot is checked against the end when it is
+        // written: the later stages walk a queue up to its end, so every slot below it that has been reserved must be written
+        // (a queue's counter beyond its end reports the frame incomplete).
         uint32_t shadeSlot = 0xffffffffu, leafSlot = 0xffffffffu, raySlot = 0xffffffffu;
         {
             const uint32_t N = F.numGlossySamples;
-            reserve_slots3(P.qCount + 0, P.shadeCap, wantShade ? 1u : (wantConsume ? nHits : 0u), P.qCount + 1, P.leafCap,
+            reserve_slots3(P.qCount + 0, 0xffffffffu, wantShade ? 1u : (wantConsume ? nHits : 0u), P.qCount + 1, 0xffffffffu,
                            wantLeaf ? 1u : (wantConsume ? N * nOpened : 0u), P.rayCountOut, P.rayCap, wantBatch ? batchKids * (batchKids + 1) / 2 : 0u, lane, s_n,
                            s_base, shadeSlot, leafSlot, raySlot);
         }
@@ -1247,7 +1250,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
         if (__ballot(wantShade) != 0ull) {
             const bool pushFrame = wantShade && (openLoop || openPass);
             if (wantShade) {
-                if (shadeSlot != 0xffffffffu) {
+                if (shadeSlot < P.shadeCap) {
                     const float4* src = reinterpret_cast<const float4*>(&st);
                     float4* dst = reinterpret_cast<float4*>(P.shadeQ + shadeSlot);
                     dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
@@ -1284,7 +1287,7 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
             }
         }
         if (wantLeaf) {
-            if (leafSlot != 0xffffffffu) {
+            if (leafSlot < P.leafCap) {
                 const float4* src = reinterpret_cast<const float4*>(&lt);
                 float4* dst = reinterpret_cast<float4*>(P.leafQ + leafSlot);
                 dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
@@ -1340,8 +1343,16 @@ __device__ __forceinline__ void advance_lanes(const WaveParams& P, PathLane& L, 
                 const vec3 fW = make3(f0.x, f0.y, f0.z), ks = make3(f3.x, f3.y, f3.z);
                 const int enclosing = (int)__float_as_uint(f4.y) - 1;
                 const vec3 cw = fW * ks / float(N);
-                const bool room = (nHits == 0 || shadeBase != 0xffffffffu) && (nOpened == 0 || leafBase != 0xffffffffu);
-                if (!room) cDrop++;
+                // all of the batch's tasks or none: what was reserved below a queue's end and stays unused becomes holes
+                const bool room = (nHits == 0 || shadeBase + nHits <= P.shadeCap) && (nOpened == 0 || leafBase + N * nOpened <= P.leafCap);
+                if (!room) {
+                    cDrop++;
+                    for (uint32_t k = 0; k < nHits; k++)
+                        if (shadeBase + k < P.shadeCap) reinterpret_cast<uint32_t*>(P.shadeQ + shadeBase + k)[0] = kHolePixel;
+                    for (uint32_t k = 0; k < N * nOpened; k++)
+                        if (leafBase + k < P.leafCap)
+                            store_leaf_task(P.leafQ + leafBase + k, kHolePixel, splat(0.0f), make3(0.0f, 0.0f, 1.0f), -1.0f, splat(0.0f));
+                }
                 uint32_t ksel[kMaxN];
                 {
                     uint32_t opened = 0;
@@ -1524,13 +1535,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_LOGIC
             if (TRANSP) passes = P.passBase + (size_t)slot * kPassDwords;
             L.rayBase = P.activeRayIn[at];
             if (L.nRays > 1) {
-                L.state = PS_BATCH;
-            } else {
+                L.state = PS_BATCH; // (a batch's rays were reserved as a whole: all of them lie below rayCap)
+            } else if (L.rayBase < P.rayCap) {
                 const HitRec h = P.hits[L.rayBase];
                 L.tt = h.t;
                 L.ttri = h.tri;
                 L.state = PS_HIT;
-            }
+            } // else: the ray found no room in the last round (counted there, the frame is reported incomplete) - no hit record exists
+              // for it, the pixel ends here
         }
         auto alloc = [&](const bool) {}; // every state of a round already owns its frame storage
         advance_lanes<TRANSP>(P, L, frames, passes, alloc, lane, cPrimary, cSecondary, cDrop, s_n, s_base);
@@ -1991,7 +2003,7 @@ __global__ __launch_bounds__(kBlock) void shade_expand_kernel(const WaveParams P
         uint32_t s2 = smp;
         for (uint32_t k = 0; k < N; k++) {
             vec3 pd;
-            if (glossy_sample(s2, radius, w, u, v, h.normal, pd)) {
+            if (glossy_sample(s2, radius, w, u, v, h.normal, pd)) { // (a raw task's leaf slots all lie below the queue's end: path_logic_kernel)
                 cSecondary++;
                 store_leaf_task(P.leafQ + leafSlot + k, pixel, rorg + 0.0001f * pd, pd, FLT_MAX, lw);
             } else {
