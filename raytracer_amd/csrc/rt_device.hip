@@ -40,6 +40,7 @@ struct Workspace {
     void* d_shadeQ = nullptr;
     void* d_leafQ = nullptr;
     uint32_t shadeCap = 0, leafCap = 0;
+    uint32_t lastLeafCap = 0;       // leaf tasks the last frame's kernels were given room for (leafCap, or the multiple of its loop size below)
     float* d_states = nullptr;      // path states, one slot per pixel of the region: headers alone (rounds) or whole records (persistent launches)
     size_t stateWords = 0;          // ... its size in floats
     float* d_frames = nullptr;      // rounds: pending glossy loops, by rayDepth then state (WaveParams::frameBase)
@@ -2685,6 +2686,10 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     P.shadeQ = static_cast<ShadeTask*>(w.d_shadeQ), P.leafQ = static_cast<LeafTask*>(w.d_leafQ);
     P.qCount = w.d_work + 8;
     P.shadeCap = w.shadeCap, P.leafCap = w.leafCap;
+    // (the persistent schedules reserve a glossy loop's leaf slots all at once, at multiples of the loop's size: a queue that
+    // ends at such a multiple has no reservation across its end, whose slots before the end nobody would write)
+    if (usePath && features->numGlossySamples > 1) P.leafCap -= P.leafCap % features->numGlossySamples;
+    w.lastLeafCap = P.leafCap;
     P.lightDraws = lightDraws;
     P.states = w.d_states, P.stateStride = stateStride;
     // (addressed by rayDepth: the levels below firstLevel are never touched and have no storage)
@@ -3034,7 +3039,7 @@ static int render_frames_impl(rt_scene* scene, const rt_camera* camera, const in
     }
     // what the batched loops left for later: their children's hit records and the grandchildren's rays
     if (batchRays) hipLaunchKernelGGL(shade_expand_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
-    launch_trace(w.d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, w.leafCap, 1, false, 0, 1);
+    launch_trace(w.d_leafQ, sizeof(LeafTask), P.qCount + 1, 0, P.leafCap, 1, false, 0, 1);
     hipLaunchKernelGGL(leaf_logic_kernel, dim3(taskGrid), dim3(kBlock), 0, st, P);
     for (uint32_t c = 0; c < nChunks; c++) {
         P.chunkBase = c * chunkTasks;
@@ -3256,13 +3261,13 @@ static int collect_frame(rt_scene* scene, Workspace& w, rt_stats* stats)
             held.shade = std::max(held.shade, (double)q[0] / (double)w.lastWork);
             held.leaf = std::max(held.leaf, (double)q[1] / (double)w.lastWork);
         }
-        if (q[0] > w.shadeCap || q[1] > w.leafCap) {
+        if (q[0] > w.shadeCap || q[1] > w.lastLeafCap) {
             // the next frame gets queues of the size this one asked for and a quarter more
-            const bool canGrow = (q[0] > w.shadeCap && w.shadeCap < kMaxQueueTasks) || (q[1] > w.leafCap && w.leafCap < kMaxQueueTasks);
+            const bool canGrow = (q[0] > w.shadeCap && w.shadeCap < kMaxQueueTasks) || (q[1] > w.lastLeafCap && w.leafCap < kMaxQueueTasks);
             // (leaf tasks that found no room left no shade task behind: the shade queue is sized for every leaf ray hitting)
             const uint64_t most = std::max(q[0], q[1]);
             scene->wantShadeTasks = std::max<uint64_t>(scene->wantShadeTasks, most + most / 4);
-            if (q[1] > w.leafCap) scene->wantLeafTasks = std::max<uint64_t>(scene->wantLeafTasks, (uint64_t)q[1] + q[1] / 4);
+            if (q[1] > w.lastLeafCap) scene->wantLeafTasks = std::max<uint64_t>(scene->wantLeafTasks, (uint64_t)q[1] + q[1] / 4);
             rt::set_error("task queues overflowed (%u shade tasks for %u slots, %u leaf tasks for %u slots): the frame is incomplete; %s",
                           q[0], w.shadeCap, q[1], w.leafCap,
                           canGrow ? "the queues grow with the next rt_render of this scene: render the frame again"
