@@ -21,7 +21,7 @@ grep -h '"metric"' $out/kt.log > $out/bench_under_rocprof.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kts -o p -- python3 $root/bench.py --frames-in-flight 1 --frames-per-sequence 8 --steps 16 --warmup 8 --cpu-seconds 0 > $out/kts.log 2>&1 || { tail -5 $out/kts.log; exit 1; }
 cp $out/kts/p_kernel_stats.csv $out/kernel_stats_sequence.csv
 grep -h '"metric"' $out/kts.log > $out/bench_under_rocprof_sequence.json
-# the bench's defaults: sequences on four streams, kernels of different sequences overlap, durations stretch
+# the bench's defaults: sequences on three streams (four from 32 steps on), kernels of different sequences overlap, durations stretch
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kto -o p -- python3 $root/bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $out/kto.log 2>&1 || { tail -5 $out/kto.log; exit 1; }
 cp $out/kto/p_kernel_stats.csv $out/kernel_stats_overlapped.csv
 grep -h '"metric"' $out/kto.log > $out/bench_under_rocprof_overlapped.json
