@@ -218,6 +218,8 @@ def main():
             dist.all_reduce(probe_ms, op=dist.ReduceOp.MAX)
         if float(probe_ms.item()) < 3.0:
             K = 2
+            if whole and not args.frames_in_flight:
+                F = 4  # (frames bound by their copies: 20 glossy x1 steps 0.91 ms per step on four streams, 1.03 on three)
         del probe
         scene.trim()  # the probe's buffers (a scene's first frame is given room for the worst case); what it held sizes the sequences' buffers
     if by_frames:  # every rank cuts its own frames into sequences of the same size: the smallest any rank arrived at
